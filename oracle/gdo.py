@@ -1,0 +1,194 @@
+"""ctypes front-end of the CPU oracle (oracle/libgdo.so) and, where it has been built, of the reference itself
+(oracle/_ref/libgdiet_*.so).  TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg,
+__graft_entry__.smoke() and the pin/fixture scripts under oracle/ -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+NEG_INF = -0x40000000
+EZ_SCORE_ONLY, EZ_RIGHT, EZ_GENERIC_SC, EZ_APPROX_MAX, EZ_APPROX_DROP, EZ_EXTZ_ONLY, EZ_REV_CIGAR = 1, 2, 4, 8, 0x10, 0x40, 0x80
+
+
+class GdoExtz(C.Structure):
+    _fields_ = [("max", C.c_uint32), ("zdropped", C.c_int), ("max_q", C.c_int), ("max_t", C.c_int),
+                ("mqe", C.c_int), ("mqe_t", C.c_int), ("mte", C.c_int), ("mte_q", C.c_int), ("score", C.c_int),
+                ("m_cigar", C.c_int), ("n_cigar", C.c_int), ("reach_end", C.c_int), ("cigar", C.POINTER(C.c_uint32))]
+
+
+class RefExtz(C.Structure):  # ksw_extz_t of the reference (ksw2.h:31-40): max:31|zdropped:1 share one word
+    _fields_ = [("max_zd", C.c_uint32), ("max_q", C.c_int), ("max_t", C.c_int),
+                ("mqe", C.c_int), ("mqe_t", C.c_int), ("mte", C.c_int), ("mte_q", C.c_int), ("score", C.c_int),
+                ("m_cigar", C.c_int), ("n_cigar", C.c_int), ("reach_end", C.c_int), ("cigar", C.POINTER(C.c_uint32))]
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def load_oracle():
+    path = os.path.join(HERE, "libgdo.so")
+    if not os.path.exists(path):
+        build_oracle()
+    lib = C.CDLL(path)
+    u8p, i8p = C.POINTER(C.c_uint8), C.POINTER(C.c_int8)
+    lib.gdo_ksw_extd2.argtypes = [C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GdoExtz)]
+    lib.gdo_ksw_extz2.argtypes = [C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GdoExtz)]
+    lib.gdo_exact_match.argtypes = [C.c_int, u8p, C.c_int, u8p]
+    lib.gdo_exact_match.restype = C.c_int
+    return lib
+
+
+def have_ref(variant="lr_avx"):
+    return os.path.exists(os.path.join(HERE, "_ref", "libgdiet_%s.so" % variant))
+
+
+def load_ref(variant="lr_avx"):
+    lib = C.CDLL(os.path.join(HERE, "_ref", "libgdiet_%s.so" % variant))
+    u8p, i8p = C.POINTER(C.c_uint8), C.POINTER(C.c_int8)
+    d2 = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+          C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RefExtz)]
+    lib.ksw_extd2_sse.argtypes = d2
+    if hasattr(lib, "ksw_extd2_avx512"):
+        lib.ksw_extd2_avx512.argtypes = d2
+    lib.ksw_extz2_sse.argtypes = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RefExtz)]
+    lib.exact_match_sse.argtypes = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RefExtz), C.POINTER(C.c_bool),
+                                    C.POINTER(C.c_int)]
+    return lib
+
+
+def score_matrix(a, b, m=5):
+    """mat[25] as built at every call site of the live path (LR/map.c:1736-1740)."""
+    bb = b if b < 0 else -b
+    mat = np.full((m, m), bb, dtype=np.int8)
+    for i in range(m - 1):
+        mat[i, i] = a
+    mat[m - 1, :] = 0
+    mat[:, m - 1] = 0
+    return np.ascontiguousarray(mat.reshape(-1))
+
+
+def _p(arr, ty):
+    return arr.ctypes.data_as(C.POINTER(ty))
+
+
+def _result(ez, zdropped, mx):
+    n = ez.n_cigar
+    cig = np.ctypeslib.as_array(ez.cigar, shape=(n,)).copy() if n > 0 else np.zeros(0, np.uint32)
+    if ez.cigar:
+        _libc.free(C.cast(ez.cigar, C.c_void_p))
+    return dict(score=ez.score, cigar=cig.astype(np.uint32), zdropped=int(zdropped), max=int(mx), max_q=ez.max_q,
+                max_t=ez.max_t, mqe=ez.mqe, mqe_t=ez.mqe_t, mte=ez.mte, mte_q=ez.mte_q, reach_end=ez.reach_end)
+
+
+def oracle_extd2(lib, query, target, mat, q, e, q2, e2, w, zdrop=-1, end_bonus=0, flag=EZ_APPROX_MAX, m=5):
+    ez = GdoExtz()
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    lib.gdo_ksw_extd2(len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8), m, _p(mat, C.c_int8),
+                      q, e, q2, e2, w, zdrop, end_bonus, flag, C.byref(ez))
+    return _result(ez, ez.zdropped, ez.max)
+
+
+def oracle_extz2(lib, query, target, mat, q, e, w, zdrop=-1, end_bonus=0, flag=EZ_APPROX_MAX, m=5):
+    ez = GdoExtz()
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    lib.gdo_ksw_extz2(len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8), m, _p(mat, C.c_int8),
+                      q, e, w, zdrop, end_bonus, flag, C.byref(ez))
+    return _result(ez, ez.zdropped, ez.max)
+
+
+def oracle_exact_match(lib, query, target):
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    return lib.gdo_exact_match(len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8))
+
+
+def ref_extd2(lib, query, target, mat, q, e, q2, e2, w, zdrop=-1, end_bonus=0, flag=EZ_APPROX_MAX, m=5, fn="ksw_extd2_sse"):
+    ez = RefExtz()
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    getattr(lib, fn)(None, len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8), m, _p(mat, C.c_int8),
+                     q, e, q2, e2, w, zdrop, end_bonus, flag, C.byref(ez))
+    return _result(ez, ez.max_zd >> 31, ez.max_zd & 0x7fffffff)
+
+
+def ref_extz2(lib, query, target, mat, q, e, w, zdrop=-1, end_bonus=0, flag=EZ_APPROX_MAX, m=5):
+    ez = RefExtz()
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    lib.ksw_extz2_sse(None, len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8), m, _p(mat, C.c_int8),
+                      q, e, w, zdrop, end_bonus, flag, C.byref(ez))
+    return _result(ez, ez.max_zd >> 31, ez.max_zd & 0x7fffffff)
+
+
+def ref_exact_match(lib, query, target, mat):
+    ez = RefExtz()
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    ok, mm = C.c_bool(False), C.c_int(0)
+    lib.exact_match_sse(None, len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8), 5, _p(mat, C.c_int8),
+                        0, 0, 0, 0, 0, 0, C.byref(ez), C.byref(ok), C.byref(mm))
+    return int(ok.value)
+
+
+def same(a, b, keys=("score", "zdropped")):
+    return all(a[k] == b[k] for k in keys) and len(a["cigar"]) == len(b["cigar"]) and bool(np.all(a["cigar"] == b["cigar"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# deterministic synthetic alignment pairs (SURVEY 8d "ksw pairs" + band-edge stress); numpy Generator, fixed seeds
+# ---------------------------------------------------------------------------------------------------------------
+PRESETS = {  # a, b, q, e, q2, e2  (options.c:134,106,45 of the reference)
+    "sr": (2, 8, 12, 2, 24, 1),
+    "hifi": (1, 4, 6, 2, 26, 1),
+    "ont": (2, 4, 4, 2, 24, 1),
+}
+
+
+def mutate(rng, seq, sub, ins, dele, n_frac=0.0):
+    out = []
+    for c in seq:
+        r = rng.random()
+        if r < dele:
+            continue
+        if r < dele + ins:
+            out.append(rng.integers(0, 4))
+        if rng.random() < sub:
+            c = (c + rng.integers(1, 4)) & 3
+        if n_frac and rng.random() < n_frac:
+            c = 4
+        out.append(c)
+    return np.array(out, dtype=np.uint8)
+
+
+def make_pair(rng, tlen, sub=0.01, ins=0.003, dele=0.003, n_frac=0.0, big_indel=0, trim=0):
+    target = rng.integers(0, 4, size=tlen, dtype=np.uint8)
+    query = mutate(rng, target, sub, ins, dele, n_frac)
+    if big_indel > 0 and len(query) > 2 * big_indel + 4:  # one long insertion in the query
+        pos = int(rng.integers(1, len(query) - 1))
+        query = np.concatenate([query[:pos], rng.integers(0, 4, size=big_indel, dtype=np.uint8), query[pos:]])
+    elif big_indel < 0 and len(query) > -2 * big_indel + 4:  # one long deletion from the query
+        pos = int(rng.integers(1, len(query) + big_indel - 1))
+        query = np.concatenate([query[:pos], query[pos - big_indel:]])
+    if n_frac:
+        target = target.copy()
+        target[rng.random(tlen) < n_frac] = 4
+    if trim:
+        query = query[: max(1, len(query) - trim)]
+    if len(query) == 0:
+        query = np.zeros(1, np.uint8)
+    return np.ascontiguousarray(query), np.ascontiguousarray(target)
