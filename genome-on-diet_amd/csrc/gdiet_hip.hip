@@ -1,0 +1,365 @@
+// C-ABI shim (include/gdiet_hip.h) over the HIP kernels.  Host side is plain C++; no torch types anywhere.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/gdiet_hip.h"
+#include "ksw_common.h"
+#include "ksw_generic.hip.h"
+#include "ksw_backtrack.hip.h"
+#include "ksw_wave.hip.h"
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct gdiet_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	char name[256] = {0};
+	int kernel_mode = 0;
+	int last_mask = 0;
+	DevBuf arena;               // backtrace matrices
+	DevBuf tasks, ids, status;  // per-batch descriptors
+	DevBuf qseq, tseq, score, ncig, cigar; // host-API staging
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	std::vector<KswTask> h_tasks;
+	std::vector<int32_t> h_ids;
+};
+
+#define GD_HIP(call)                                                                              \
+	do {                                                                                          \
+		hipError_t e__ = (call);                                                                  \
+		if (e__ != hipSuccess) {                                                                  \
+			ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);                        \
+			return GDIET_E_HIP;                                                                   \
+		}                                                                                         \
+	} while (0)
+
+static int gd_grow(gdiet_ctx *ctx, DevBuf &b, size_t bytes)
+{
+	if (bytes <= b.cap) return GDIET_OK;
+	// growth is rare (first batches); it synchronises the stream because older work may still read the buffer
+	GD_HIP(hipStreamSynchronize(ctx->stream));
+	if (b.p) GD_HIP(hipFree(b.p));
+	b.p = nullptr, b.cap = 0;
+	size_t want = bytes + (bytes >> 3) + 4096;
+	hipError_t e = hipMalloc(&b.p, want);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		want = bytes;
+		e = hipMalloc(&b.p, want);
+	}
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		ctx->err = "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e);
+		b.p = nullptr;
+		return GDIET_E_NOMEM;
+	}
+	b.cap = want;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
+{
+	if (!out) return GDIET_E_PARAM;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return GDIET_E_NODEVICE;
+	gdiet_ctx *ctx = new gdiet_ctx();
+	ctx->device = device;
+	hipDeviceProp_t prop;
+	if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+		delete ctx;
+		return GDIET_E_NODEVICE;
+	}
+	snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { // the code object is gfx950-only; fail loudly, no fallback
+		delete ctx;
+		return GDIET_E_NODEVICE;
+	}
+	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete ctx;
+		return GDIET_E_HIP;
+	}
+	for (int i = 0; i < 4; ++i)
+		if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
+			delete ctx;
+			return GDIET_E_HIP;
+		}
+	*out = ctx;
+	return GDIET_OK;
+}
+
+extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar};
+	for (DevBuf *b : bufs)
+		if (b->p) (void)hipFree(b->p);
+	for (int i = 0; i < 4; ++i)
+		if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+extern "C" const char *gdiet_hip_strerror(const gdiet_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+extern "C" int gdiet_hip_device_name(const gdiet_ctx *ctx, char *buf, size_t len)
+{
+	if (!ctx || !buf || !len) return GDIET_E_PARAM;
+	snprintf(buf, len, "%s", ctx->name);
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_last_kernel_mask(const gdiet_ctx *ctx) { return ctx ? ctx->last_mask : 0; }
+
+extern "C" int gdiet_hip_set_kernel_mode(gdiet_ctx *ctx, int mode)
+{
+	if (!ctx || mode < 0 || mode > 2) return GDIET_E_PARAM;
+	ctx->kernel_mode = mode;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_reserve(gdiet_ctx *ctx, size_t bytes)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	return gd_grow(ctx, ctx->arena, bytes);
+}
+
+// ---- planning ----------------------------------------------------------------------------------------------
+
+// number of cells the generic kernel's LDS ring must hold for this geometry (see ksw_generic.hip.h)
+static int gd_generic_cap(int qlen, int tlen, int w)
+{
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	int n = std::min(std::min(qlen, tlen), w + 1);
+	int need = n + 64, cap = 256;
+	while (cap < need) cap <<= 1;
+	return cap;
+}
+
+static inline size_t gd_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// decide kernel + backtrace geometry of one alignment
+static void gd_plan_one(int mode, int qlen, int tlen, int w, int32_t &kind, int32_t &row_bytes)
+{
+	const int ncol = gd_ncol16(qlen, tlen, w);
+	kind = GD_KIND_GENERIC, row_bytes = ncol * 16;
+	if (mode == 1) return;
+	if (gd_wave_supported(qlen, tlen, w, 64)) {
+		if (gd_wave_supported(qlen, tlen, w, 16)) kind = GD_KIND_WAVE16, row_bytes = 16 * 16;
+		else kind = GD_KIND_WAVE64, row_bytes = 64 * 16;
+	}
+}
+
+extern "C" size_t gdiet_hip_ksw_workspace_bytes(int n, const int64_t *qoff, const int64_t *toff, const int32_t *w)
+{
+	size_t tot = 0;
+	for (int i = 0; i < n; ++i) {
+		const int qlen = (int)(qoff[i + 1] - qoff[i]), tlen = (int)(toff[i + 1] - toff[i]);
+		if (qlen <= 0 || tlen <= 0) continue;
+		int32_t kind, rb;
+		gd_plan_one(0, qlen, tlen, w[i], kind, rb);
+		const size_t a = (size_t)(qlen + tlen - 1) * (size_t)rb;
+		const size_t b = (size_t)(qlen + tlen - 1) * (size_t)gd_ncol16(qlen, tlen, w[i]) * 16; // forced-generic worst case
+		tot += gd_align256(std::max(a, b) + 64);
+	}
+	return tot;
+}
+
+static int gd_consts(gdiet_ctx *ctx, const gdiet_ksw_score_t *sc, KswConst &K)
+{
+	if (!sc) { ctx->err = "scoring is NULL"; return GDIET_E_PARAM; }
+	if (sc->flag != GDIET_EZ_APPROX_MAX) {
+		ctx->err = "only flag == GDIET_EZ_APPROX_MAX (the live path's mode) is implemented";
+		return GDIET_E_PARAM;
+	}
+	int q = sc->q, e = sc->e, q2 = sc->q2, e2 = sc->e2;
+	if (q2 + e2 < q + e) std::swap(q, q2), std::swap(e, e2); // SR/ksw2_extd2_sse.c:78
+	K.q = q, K.e = e, K.q2 = q2, K.e2 = e2;
+	K.sc_mch = sc->match, K.sc_mis = sc->mismatch;
+	K.sc_N = sc->sc_ambi == 0 ? -e2 : sc->sc_ambi;
+	// :96-100 early return "if (-min_sc > 2 * (q + e)) return" leaves score = NEG_INF for every pair; the live
+	// path can never get there (mm_check_opt), so it is reported as a parameter error instead.
+	int min_sc = std::min<int>(std::min<int>(sc->mismatch, sc->match), std::min<int>(sc->sc_ambi, 0));
+	if (-min_sc > 2 * (q + e)) { ctx->err = "-min_sc > 2*(q+e): the reference returns without aligning"; return GDIET_E_PARAM; }
+	if ((q + e) + (q2 + e2) > 127) { ctx->err = "(q+e)+(q2+e2) > 127 (mm_check_opt, options.c:218)"; return GDIET_E_PARAM; }
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	K.long_thres = long_thres;
+	K.long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	return GDIET_OK;
+}
+
+// ---- device-pointer entry point ----------------------------------------------------------------------------
+
+extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const int64_t *d_qoff,
+                                             const uint8_t *d_tseq, const int64_t *d_toff, const int32_t *d_w,
+                                             const int32_t *d_exact_score, const gdiet_ksw_score_t *sc,
+                                             int32_t *d_score, int32_t *d_n_cigar, uint32_t *d_cigar,
+                                             const int64_t *d_cigar_off, const int64_t *h_qoff, const int64_t *h_toff,
+                                             const int32_t *h_w, void *stream_)
+{
+	(void)d_qoff, (void)d_toff, (void)d_w;
+	if (!ctx) return GDIET_E_PARAM;
+	if (n <= 0) return GDIET_OK;
+	if (!d_qseq || !d_tseq || !d_score || !d_n_cigar || !d_cigar || !h_qoff || !h_toff || !h_w) {
+		ctx->err = "NULL argument";
+		return GDIET_E_PARAM;
+	}
+	(void)hipSetDevice(ctx->device);
+	hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+	KswConst K;
+	int rc = gd_consts(ctx, sc, K);
+	if (rc) return rc;
+	// d_cigar_off / d_exact_score are small: planning needs them on the host
+	std::vector<int64_t> h_cig(n + 1);
+	GD_HIP(hipMemcpyAsync(h_cig.data(), d_cigar_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, stream));
+	std::vector<int32_t> h_ex;
+	if (d_exact_score) {
+		h_ex.resize(n);
+		GD_HIP(hipMemcpyAsync(h_ex.data(), d_exact_score, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream));
+	}
+	GD_HIP(hipStreamSynchronize(stream));
+
+	ctx->h_tasks.resize(n);
+	size_t bt = 0;
+	std::vector<int32_t> ids[3];
+	int max_cap = 0;
+	ctx->last_mask = 0;
+	for (int i = 0; i < n; ++i) {
+		KswTask &T = ctx->h_tasks[i];
+		T.qoff = h_qoff[i], T.toff = h_toff[i];
+		T.qlen = (int)(h_qoff[i + 1] - h_qoff[i]), T.tlen = (int)(h_toff[i + 1] - h_toff[i]);
+		T.w = h_w[i];
+		T.cig_off = h_cig[i], T.cig_cap = (int32_t)std::min<int64_t>(h_cig[i + 1] - h_cig[i], 0x7fffffff);
+		T.exact_score = d_exact_score ? h_ex[i] : GD_NEG_INF;
+		T.pad = 0;
+		if (T.qlen <= 0 || T.tlen <= 0) { ctx->err = "empty sequence in batch (the reference returns without aligning)"; return GDIET_E_PARAM; }
+		gd_plan_one(ctx->kernel_mode, T.qlen, T.tlen, T.w, T.kind, T.row_bytes);
+		if (ctx->kernel_mode == 2 && T.kind == GD_KIND_GENERIC) { ctx->err = "alignment does not fit the wave kernel"; return GDIET_E_PARAM; }
+		if (T.kind == GD_KIND_GENERIC) {
+			int cap = gd_generic_cap(T.qlen, T.tlen, T.w);
+			if (cap * 7 > 160 * 1024 - 1024) { ctx->err = "band wider than the LDS window of the generic kernel"; return GDIET_E_PARAM; }
+			max_cap = std::max(max_cap, cap);
+		}
+		T.bt_off = (int64_t)bt;
+		bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
+		ids[T.kind].push_back(i);
+		ctx->last_mask |= T.kind == GD_KIND_GENERIC ? 2 : 1;
+	}
+	// longest alignments first inside each class: the tail of the grid is then made of short jobs
+	for (int k = 0; k < 3; ++k)
+		std::stable_sort(ids[k].begin(), ids[k].end(), [&](int a, int b) {
+			const KswTask &A = ctx->h_tasks[a], &B = ctx->h_tasks[b];
+			return (int64_t)A.qlen + A.tlen > (int64_t)B.qlen + B.tlen;
+		});
+	ctx->h_ids.clear();
+	size_t id_off[3];
+	for (int k = 0; k < 3; ++k) {
+		id_off[k] = ctx->h_ids.size();
+		ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
+	}
+	if ((rc = gd_grow(ctx, ctx->arena, bt))) return rc;
+	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->status, sizeof(int32_t) * n))) return rc;
+	GD_HIP(hipMemcpyAsync(ctx->tasks.p, ctx->h_tasks.data(), sizeof(KswTask) * n, hipMemcpyHostToDevice, stream));
+	GD_HIP(hipMemcpyAsync(ctx->ids.p, ctx->h_ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
+
+	const KswTask *d_tasks = (const KswTask *)ctx->tasks.p;
+	const int32_t *d_ids = (const int32_t *)ctx->ids.p;
+	int32_t *d_status = (int32_t *)ctx->status.p;
+	uint8_t *d_bt = (uint8_t *)ctx->arena.p;
+
+	GD_HIP(hipEventRecord(ctx->ev[0], stream));
+	hipLaunchKernelGGL(ksw_exact_match_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_qseq, d_tseq,
+	                   d_status, d_score, d_n_cigar, d_cigar);
+	if (!ids[GD_KIND_WAVE64].empty())
+		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], (int)ids[GD_KIND_WAVE64].size(), d_qseq, d_tseq, d_bt,
+		                 d_status, d_score, K, stream);
+	if (!ids[GD_KIND_WAVE16].empty())
+		gd_launch_wave16(d_tasks, d_ids + id_off[GD_KIND_WAVE16], (int)ids[GD_KIND_WAVE16].size(), d_qseq, d_tseq, d_bt,
+		                 d_status, d_score, K, stream);
+	if (!ids[GD_KIND_GENERIC].empty()) {
+		const size_t lds = (size_t)max_cap * 7;
+		if (lds > 64 * 1024)
+			GD_HIP(hipFuncSetAttribute((const void *)ksw_extd2_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL(ksw_extd2_generic_kernel, dim3((unsigned)ids[GD_KIND_GENERIC].size()), dim3(64), lds, stream,
+		                   d_tasks, d_ids + id_off[GD_KIND_GENERIC], d_qseq, d_tseq, d_bt, d_status, d_score, K, max_cap);
+	}
+	GD_HIP(hipEventRecord(ctx->ev[1], stream));
+	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_bt, d_status, d_score,
+	                   d_n_cigar, d_cigar);
+	GD_HIP(hipEventRecord(ctx->ev[2], stream));
+	GD_HIP(hipGetLastError());
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *bt_ms)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	float a = 0, b = 0;
+	GD_HIP(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+	GD_HIP(hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+	if (dp_ms) *dp_ms = a;
+	if (bt_ms) *bt_ms = b;
+	return GDIET_OK;
+}
+
+// ---- host-pointer entry point ------------------------------------------------------------------------------
+
+extern "C" int gdiet_hip_ksw_extd2_batch(gdiet_ctx *ctx, int n, const uint8_t *qseq, const int64_t *qoff,
+                                         const uint8_t *tseq, const int64_t *toff, const int32_t *w,
+                                         const int32_t *exact_score, const gdiet_ksw_score_t *sc, int32_t *score,
+                                         int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	if (n <= 0) return GDIET_OK;
+	if (!qseq || !qoff || !tseq || !toff || !w || !score || !n_cigar || !cigar || !cigar_off) {
+		ctx->err = "NULL argument";
+		return GDIET_E_PARAM;
+	}
+	(void)hipSetDevice(ctx->device);
+	int rc;
+	hipStream_t s = ctx->stream;
+	const size_t qb = (size_t)qoff[n], tb = (size_t)toff[n], cb = (size_t)cigar_off[n];
+	// layout of the small per-batch arrays behind the sequences: [cigar_off (n+1) i64][exact (n) i32]
+	const size_t aux = sizeof(int64_t) * (n + 1) + sizeof(int32_t) * n;
+	if ((rc = gd_grow(ctx, ctx->qseq, qb + 64))) return rc;
+	if ((rc = gd_grow(ctx, ctx->tseq, tb + 64 + aux + 16))) return rc;
+	if ((rc = gd_grow(ctx, ctx->score, sizeof(int32_t) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->ncig, sizeof(int32_t) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->cigar, sizeof(uint32_t) * (cb + 1)))) return rc;
+	uint8_t *d_q = (uint8_t *)ctx->qseq.p, *d_t = (uint8_t *)ctx->tseq.p;
+	int64_t *d_cigoff = (int64_t *)(d_t + ((tb + 64 + 15) & ~(size_t)15));
+	int32_t *d_ex = (int32_t *)(d_cigoff + n + 1);
+	GD_HIP(hipMemcpyAsync(d_q, qseq, qb, hipMemcpyHostToDevice, s));
+	GD_HIP(hipMemcpyAsync(d_t, tseq, tb, hipMemcpyHostToDevice, s));
+	GD_HIP(hipMemcpyAsync(d_cigoff, cigar_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s));
+	if (exact_score) GD_HIP(hipMemcpyAsync(d_ex, exact_score, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+	rc = gdiet_hip_ksw_extd2_batch_dev(ctx, n, d_q, nullptr, d_t, nullptr, nullptr, exact_score ? d_ex : nullptr, sc,
+	                                   (int32_t *)ctx->score.p, (int32_t *)ctx->ncig.p, (uint32_t *)ctx->cigar.p, d_cigoff,
+	                                   qoff, toff, w, s);
+	if (rc) return rc;
+	GD_HIP(hipMemcpyAsync(score, ctx->score.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipMemcpyAsync(n_cigar, ctx->ncig.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipMemcpyAsync(cigar, ctx->cigar.p, sizeof(uint32_t) * cb, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipStreamSynchronize(s));
+	for (int i = 0; i < n; ++i)
+		if (n_cigar[i] > cigar_off[i + 1] - cigar_off[i]) {
+			ctx->err = "CIGAR of alignment " + std::to_string(i) + " needs " + std::to_string(n_cigar[i]) + " ops";
+			return GDIET_E_CIGAR_CAP;
+		}
+	return GDIET_OK;
+}

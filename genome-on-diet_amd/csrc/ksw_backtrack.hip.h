@@ -1,0 +1,105 @@
+// K0 (exact-match pre-filter, SR/exact_match_sse.c:23-91) and K2 (ksw_backtrack, SR/ksw2.h:131-163).
+// Both are one-thread-per-alignment kernels: K0 is a byte compare of <300 bp, K2 a dependent pointer chase of
+// qlen+tlen one-byte loads whose latency is hidden by running thousands of alignments side by side.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ksw_common.h"
+
+// position of cell (r, i) inside a backtrace row, for the two layouts the DP kernels write
+//   generic: the reference's own layout, column i - off[r] with off[r] = st0(r)/16*16 (SR/ksw2.h:142)
+//   wave:    lane-major ring: 16-cell block i>>4 lives in lane (i>>4) mod L (L = row_bytes/16); inside the
+//            16 bytes of a lane cells are stored in the order the packed registers hold them
+//            (byte 4g+h holds cell 2g+(h&1)+8*(h>>1): cells k, k+1, k+8, k+9 of register pair g; see ksw_wave.hip.h)
+__device__ __forceinline__ size_t gd_bt_index(const KswTask &T, int r, int i, int off)
+{
+	if (T.kind == GD_KIND_GENERIC) return (size_t)r * T.row_bytes + (size_t)(i - off);
+	const int lanes = T.row_bytes >> 4;
+	const int c = i & 15;
+	const int g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
+	return (size_t)r * T.row_bytes + (size_t)(((i >> 4) & (lanes - 1)) << 4) + (g << 2) + h;
+}
+
+__global__ __launch_bounds__(64) void ksw_exact_match_kernel(const KswTask *__restrict__ tasks, int n,
+                                                             const uint8_t *__restrict__ qseq,
+                                                             const uint8_t *__restrict__ tseq,
+                                                             int32_t *__restrict__ status, int32_t *__restrict__ score,
+                                                             int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
+{
+	const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (tid >= n) return;
+	const KswTask T = tasks[tid];
+	int st = GD_ST_PENDING;
+	if (T.exact_score != GD_NEG_INF && T.qlen == T.tlen && T.qlen > 0) {
+		const uint8_t *q = qseq + T.qoff, *t = tseq + T.toff;
+		bool eq = true;
+		for (int k = 0; k < T.qlen; ++k) eq &= q[k] == t[k];
+		if (eq) {
+			st = GD_ST_EXACT;
+			score[tid] = T.exact_score;
+			n_cigar[tid] = 1;
+			if (T.cig_cap >= 1) cigar[T.cig_off] = (uint32_t)T.qlen << 4; // "<qlen>M", LR/map.c:1783-1784
+		}
+	}
+	status[tid] = st;
+}
+
+__global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__restrict__ tasks, int n,
+                                                           const uint8_t *__restrict__ bt,
+                                                           const int32_t *__restrict__ status,
+                                                           int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
+                                                           uint32_t *__restrict__ cigar)
+{
+	const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (tid >= n) return;
+	const int st = status[tid];
+	if (st == GD_ST_EXACT) return;
+	if (st != GD_ST_DONE) { // band emptied (zdropped): no CIGAR, score stays KSW_NEG_INF (SR/ksw2_extd2_sse.c:142-145,391)
+		n_cigar[tid] = 0;
+		if (st == GD_ST_ZDROPPED) score[tid] = GD_NEG_INF;
+		return;
+	}
+	const KswTask T = tasks[tid];
+	const int qlen = T.qlen, tlen = T.tlen;
+	const int w = T.w < 0 ? (tlen > qlen ? tlen : qlen) : T.w;
+	const uint8_t *p = bt + T.bt_off;
+	uint32_t *cg = cigar + T.cig_off;
+	const int cap = T.cig_cap;
+	int nc = 0, i = tlen - 1, j = qlen - 1, state = 0;
+	uint32_t last = 0; // the op run being extended (kept in a register, flushed on change)
+	int have = 0;
+#define GD_PUSH(op_, len_)                                                       \
+	do {                                                                         \
+		if (have && (last & 0xf) == (uint32_t)(op_)) last += (uint32_t)(len_) << 4; \
+		else {                                                                   \
+			if (have) { if (nc < cap) cg[nc] = last; ++nc; }                     \
+			last = (uint32_t)(len_) << 4 | (uint32_t)(op_), have = 1;            \
+		}                                                                        \
+	} while (0)
+	while (i >= 0 && j >= 0) {
+		const int r = i + j;
+		int st0, en0;
+		gd_band(r, qlen, tlen, w, st0, en0);
+		const int off = st0 & ~15, off_end = en0 | 15;
+		int force_state = -1;
+		if (i < off) force_state = 2;
+		if (i > off_end) force_state = 1;
+		const uint32_t tmp = force_state < 0 ? p[gd_bt_index(T, r, i, off)] : 0;
+		if (state == 0) state = tmp & 7;
+		else if (!(tmp >> (state + 2) & 1)) state = 0;
+		if (state == 0) state = tmp & 7;
+		if (force_state >= 0) state = force_state;
+		if (state == 0) { GD_PUSH(0, 1); --i, --j; }
+		else if (state == 1 || state == 3) { GD_PUSH(2, 1); --i; }
+		else { GD_PUSH(1, 1); --j; }
+	}
+	if (i >= 0) GD_PUSH(2, i + 1);
+	if (j >= 0) GD_PUSH(1, j + 1);
+	if (have) { if (nc < cap) cg[nc] = last; ++nc; }
+#undef GD_PUSH
+	n_cigar[tid] = nc;
+	if (nc <= cap)
+		for (int k = 0; k < nc >> 1; ++k) {
+			const uint32_t t0 = cg[k];
+			cg[k] = cg[nc - 1 - k], cg[nc - 1 - k] = t0;
+		}
+}

@@ -1,0 +1,161 @@
+"""ctypes binding of include/gdiet_hip.h.  Mirrors the reference's call shapes:
+
+``Context.ksw_extd2_batch`` is the batched form of ``ksw_extd2_sse(km, qlen, query, tlen, target, m, mat, q, e, q2,
+e2, w, zdrop, end_bonus, flag, ez)`` (reference ksw2.h:68) + the exact-match pre-filter of map.c; argument meaning
+and results (``score``, BAM-encoded ``cigar``) are the reference's.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NEG_INF = -0x40000000
+EZ_APPROX_MAX = 0x08
+
+# (a, b, q, e, q2, e2) of the three presets; reference options.c:134 (sr), :106 (map-hifi), :45 (map-ont default)
+PRESET_SCORES = {"sr": (2, 8, 12, 2, 24, 1), "hifi": (1, 4, 6, 2, 26, 1), "ont": (2, 4, 4, 2, 24, 1)}
+
+
+class GdietError(RuntimeError):
+    pass
+
+
+class KswScore(C.Structure):
+    _fields_ = [("match", C.c_int8), ("mismatch", C.c_int8), ("sc_ambi", C.c_int8), ("q", C.c_int8), ("e", C.c_int8),
+                ("q2", C.c_int8), ("e2", C.c_int8), ("reserved", C.c_int8), ("flag", C.c_int32)]
+
+    @classmethod
+    def from_preset(cls, name):
+        a, b, q, e, q2, e2 = PRESET_SCORES[name]
+        return cls(a, -b, 0, q, e, q2, e2, 0, EZ_APPROX_MAX)
+
+
+def library_path():
+    return os.path.join(HERE, "libgdiet_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libgdiet_hip.so.  torch (if it is going to be used in this process) must be imported BEFORE this so
+    that both share one HIP runtime (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise GdietError("%s is missing: run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950)" % path)
+    lib = C.CDLL(path)
+    vp, i32p, i64p, u8p, u32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    lib.gdiet_hip_init.argtypes = [C.POINTER(vp), C.c_int]
+    lib.gdiet_hip_destroy.argtypes = [vp]
+    lib.gdiet_hip_destroy.restype = None
+    lib.gdiet_hip_strerror.argtypes = [vp]
+    lib.gdiet_hip_strerror.restype = C.c_char_p
+    lib.gdiet_hip_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.gdiet_hip_last_kernel_mask.argtypes = [vp]
+    lib.gdiet_hip_set_kernel_mode.argtypes = [vp, C.c_int]
+    lib.gdiet_hip_reserve.argtypes = [vp, C.c_size_t]
+    lib.gdiet_hip_ksw_workspace_bytes.argtypes = [C.c_int, i64p, i64p, i32p]
+    lib.gdiet_hip_ksw_workspace_bytes.restype = C.c_size_t
+    lib.gdiet_hip_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.gdiet_hip_ksw_extd2_batch.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, i32p, C.POINTER(KswScore),
+                                              i32p, i32p, u32p, i64p]
+    lib.gdiet_hip_ksw_extd2_batch_dev.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(KswScore),
+                                                  vp, vp, vp, vp, i64p, i64p, i32p, vp]
+    _lib = lib
+    return lib
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def pack(seqs):
+    offs = np.zeros(len(seqs) + 1, np.int64)
+    if len(seqs):
+        offs[1:] = np.cumsum([len(s) for s in seqs])
+    buf = np.concatenate([np.asarray(s, np.uint8) for s in seqs]) if len(seqs) else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(buf, np.uint8), offs
+
+
+class Context:
+    """One GPU context (``gdiet_ctx``).  Raises GdietError when no gfx950 device is usable."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        rc = self.lib.gdiet_hip_init(C.byref(self._h), device)
+        if rc != 0:
+            raise GdietError("gdiet_hip_init(device=%d) failed with %d (no gfx950 GPU?)" % (device, rc))
+
+    def close(self):
+        if self._h:
+            self.lib.gdiet_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise GdietError("gdiet_hip error %d: %s" % (rc, self.lib.gdiet_hip_strerror(self._h).decode()))
+
+    @property
+    def device_name(self):
+        b = C.create_string_buffer(256)
+        self.lib.gdiet_hip_device_name(self._h, b, 256)
+        return b.value.decode()
+
+    def set_kernel_mode(self, mode):
+        self._check(self.lib.gdiet_hip_set_kernel_mode(self._h, mode))
+
+    def last_kernel_mask(self):
+        return self.lib.gdiet_hip_last_kernel_mask(self._h)
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._check(self.lib.gdiet_hip_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def reserve(self, nbytes):
+        self._check(self.lib.gdiet_hip_reserve(self._h, nbytes))
+
+    def workspace_bytes(self, qoff, toff, w):
+        return self.lib.gdiet_hip_ksw_workspace_bytes(len(w), _ptr(qoff, C.c_int64), _ptr(toff, C.c_int64), _ptr(w, C.c_int32))
+
+    def ksw_extd2_batch(self, queries, targets, w, score, exact_score=None):
+        """queries/targets: lists of nt4 uint8 arrays; w: int or per-pair ints; score: KswScore.
+        Returns (scores int32[n], list of uint32 CIGAR arrays)."""
+        n = len(queries)
+        qbuf, qoff = pack(queries)
+        tbuf, toff = pack(targets)
+        w = np.ascontiguousarray(np.broadcast_to(np.asarray(w, np.int32), (n,)))
+        caps = np.array([len(q) + len(t) for q, t in zip(queries, targets)], np.int64)
+        coff = np.zeros(n + 1, np.int64)
+        coff[1:] = np.cumsum(caps)
+        sc = np.zeros(n, np.int32)
+        nc = np.zeros(n, np.int32)
+        cg = np.zeros(int(coff[-1]) + 1, np.uint32)
+        ex = None if exact_score is None else np.ascontiguousarray(exact_score, np.int32)
+        rc = self.lib.gdiet_hip_ksw_extd2_batch(self._h, n, _ptr(qbuf, C.c_uint8), _ptr(qoff, C.c_int64),
+                                                _ptr(tbuf, C.c_uint8), _ptr(toff, C.c_int64), _ptr(w, C.c_int32),
+                                                None if ex is None else _ptr(ex, C.c_int32), C.byref(score),
+                                                _ptr(sc, C.c_int32), _ptr(nc, C.c_int32), _ptr(cg, C.c_uint32),
+                                                _ptr(coff, C.c_int64))
+        self._check(rc)
+        return sc, [cg[coff[i]:coff[i] + nc[i]].copy() for i in range(n)]
+
+    def ksw_extd2_batch_dev(self, n, d_qseq, d_tseq, d_exact, score, d_score, d_ncig, d_cigar, d_cigoff,
+                            h_qoff, h_toff, h_w, stream=0):
+        """device-pointer form: d_* are integer device addresses (torch tensor .data_ptr())."""
+        rc = self.lib.gdiet_hip_ksw_extd2_batch_dev(self._h, n, d_qseq, None, d_tseq, None, None, d_exact,
+                                                    C.byref(score), d_score, d_ncig, d_cigar, d_cigoff,
+                                                    _ptr(h_qoff, C.c_int64), _ptr(h_toff, C.c_int64),
+                                                    _ptr(h_w, C.c_int32), stream)
+        self._check(rc)

@@ -1,0 +1,110 @@
+/*
+ * gdiet_hip.h -- C ABI of the MI355X (gfx950) implementation of Genome-on-Diet's per-read mapping hot path.
+ *
+ * Plain C, plain pointers and sizes: this is what the reference's C host (map.c's worker loop) binds.
+ * Every entry point names the reference interface it replaces (paths relative to the reference tree;
+ * SR/ = GDiet-ShortReads/, LR/ = GDiet-LongReads/; the two trees share every file cited here unless noted).
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative GDIET_E_* code on failure; gdiet_hip_strerror() explains it.
+ *     There is NO CPU fallback inside the library: if no gfx950 device / code object is usable the call fails.
+ *   - "host" entry points take host pointers and do H2D/D2H themselves; "_dev" entry points take device
+ *     pointers (e.g. torch tensors' data_ptr()) plus a hipStream_t passed as void*, and never synchronise.
+ *   - sequences are nt4-encoded bytes 0..4 (A,C,G,T,N) exactly as the reference feeds ksw2 (LR/map.c:1622-1643,
+ *     SR/index.c:183-196 mm_idx_getseq2).
+ */
+#ifndef GDIET_HIP_H
+#define GDIET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDIET_OK            0
+#define GDIET_E_NODEVICE   (-1) /* no HIP device / not gfx950 */
+#define GDIET_E_HIP        (-2) /* a HIP runtime call failed */
+#define GDIET_E_PARAM      (-3) /* invalid or unsupported argument (see gdiet_hip_strerror) */
+#define GDIET_E_NOMEM      (-4) /* device workspace too small for the batch */
+#define GDIET_E_CIGAR_CAP  (-5) /* a CIGAR did not fit the caller's capacity (n_cigar[i] holds the needed size) */
+
+#define GDIET_KSW_NEG_INF (-0x40000000) /* KSW_NEG_INF, SR/ksw2.h:7 */
+
+/* flag bits understood by the DP entry points; numeric values of SR/ksw2.h:9-18 */
+#define GDIET_EZ_APPROX_MAX 0x08 /* the only mode the live path uses: LR/map.c:1742, SR/map.c:867 */
+
+typedef struct gdiet_ctx gdiet_ctx; /* one per (process, GPU); owns the stream(s) and the device workspace */
+
+/* scoring of one DP batch: the scalar arguments of ksw_extd2_sse (SR/ksw2.h:68-69) with the 5x5 matrix reduced
+ * to what the non-GENERIC_SC path reads (mat[0], mat[1], mat[24]; SR/ksw2_extd2_sse.c:85-87). */
+typedef struct {
+	int8_t match;      /* mat[0]   (> 0) */
+	int8_t mismatch;   /* mat[1]   (< 0) */
+	int8_t sc_ambi;    /* mat[24]  (0 on the live path => ambiguous bases score -e2) */
+	int8_t q, e, q2, e2; /* gap open / extend of the two affine models, as passed by the caller (un-swapped) */
+	int8_t reserved;
+	int32_t flag;      /* GDIET_EZ_APPROX_MAX (global alignment with CIGAR, left-aligned gaps, no z-drop) */
+} gdiet_ksw_score_t;
+
+/* ---- life cycle --------------------------------------------------------------------------------------------- */
+int gdiet_hip_init(gdiet_ctx **ctx, int device_ordinal);   /* replaces nothing: GPU context for one device */
+void gdiet_hip_destroy(gdiet_ctx *ctx);
+const char *gdiet_hip_strerror(const gdiet_ctx *ctx);       /* text of the last failure on this context */
+int gdiet_hip_device_name(const gdiet_ctx *ctx, char *buf, size_t len);
+/* which kernel variant handled the last batch: bit0 = register-resident wave kernel, bit1 = generic LDS kernel */
+int gdiet_hip_last_kernel_mask(const gdiet_ctx *ctx);
+
+/* ---- B3: batched banded dual-affine global alignment -------------------------------------------------------
+ * Replaces, for a whole batch, the per-candidate sequence of calls in mm_map_frag:
+ *     [exact_match_sse]  ->  ksw_extd2_avx512 | ksw_extd2_sse  ->  ksw_backtrack        (LR/map.c:1748-1806,
+ *     SR/map.c:873-929; kernels SR/ksw2_extd2_sse.c:34-401, SR/ksw2_extd2_avx.c:72-913, SR/ksw2.h:131-163,
+ *     SR/exact_match_sse.c:23-91).
+ *
+ * For alignment i (0 <= i < n):
+ *   query  = qseq[qoff[i] .. qoff[i+1])       target = tseq[toff[i] .. toff[i+1])
+ *   w[i]   = band width argument of ksw_extd2 (w < 0: max(qlen,tlen) as in the reference)
+ *   exact_score[i] (may be NULL): if non-NULL and exact_score[i] != GDIET_KSW_NEG_INF and qlen == tlen, the
+ *            exact-match pre-filter runs first; on a match score[i] = exact_score[i] and the CIGAR is "<qlen>M"
+ *            (the caller passes qlen_sum * a -- bug-compatibility item 5 of SURVEY 8; LR/map.c:1782).
+ * Outputs
+ *   score[i]   = ez.score (GDIET_KSW_NEG_INF if the band emptied or the corner was not reached)
+ *   n_cigar[i] = ez.n_cigar; cigar ops (BAM encoding len<<4|op, op 0=M 1=I 2=D) at cigar[cigar_off[i] ..)
+ *   the caller provides cigar_off[n+1]; capacity of alignment i is cigar_off[i+1]-cigar_off[i]
+ *   (qlen+tlen always suffices).
+ */
+int gdiet_hip_ksw_extd2_batch(gdiet_ctx *ctx, int n,
+                              const uint8_t *qseq, const int64_t *qoff,
+                              const uint8_t *tseq, const int64_t *toff,
+                              const int32_t *w, const int32_t *exact_score,
+                              const gdiet_ksw_score_t *sc,
+                              int32_t *score, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off);
+
+/* same, everything already resident in HBM (device pointers); asynchronous on `stream` (hipStream_t).
+ * Workspace for the backtrace matrices comes from the context (gdiet_hip_reserve). */
+int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n,
+                                  const uint8_t *d_qseq, const int64_t *d_qoff,
+                                  const uint8_t *d_tseq, const int64_t *d_toff,
+                                  const int32_t *d_w, const int32_t *d_exact_score,
+                                  const gdiet_ksw_score_t *sc, /* host */
+                                  int32_t *d_score, int32_t *d_n_cigar, uint32_t *d_cigar, const int64_t *d_cigar_off,
+                                  const int64_t *h_qoff, const int64_t *h_toff, const int32_t *h_w, /* host copies for planning */
+                                  void *stream);
+
+/* make sure the context owns at least `bytes` of device workspace (backtrace arena); returns GDIET_E_NOMEM
+ * if the device cannot provide it.  gdiet_hip_ksw_extd2_batch() grows the arena by itself. */
+int gdiet_hip_reserve(gdiet_ctx *ctx, size_t bytes);
+/* bytes of backtrace arena the batch (host-side lengths) needs */
+size_t gdiet_hip_ksw_workspace_bytes(int n, const int64_t *qoff, const int64_t *toff, const int32_t *w);
+/* restrict dispatch: 0 = automatic (default), 1 = force the generic LDS kernel, 2 = wave kernel only (fails
+ * with GDIET_E_PARAM for alignments it cannot take).  For tests and A/B measurements. */
+int gdiet_hip_set_kernel_mode(gdiet_ctx *ctx, int mode);
+/* average device time (ms, HIP events on the launch stream) of the DP kernel(s) and of the backtrack kernel of the
+ * most recent *_dev / host batch; only valid after the stream has been synchronised. */
+int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *backtrack_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

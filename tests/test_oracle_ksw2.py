@@ -1,0 +1,60 @@
+"""CPU: the oracle (oracle/gdo_ksw2.c) reproduces the reference's outputs stored in tests/golden/."""
+import numpy as np
+
+from golden_io import SCALARS, load_exact, load_ksw
+
+
+def test_extd2_oracle_matches_reference_golden(oracle):
+    gdo, lib = oracle
+    cases = load_ksw("ksw2_extd2")
+    assert len(cases) >= 300
+    for c in cases:
+        a, b, q, e, q2, e2 = gdo.PRESETS[c["preset"]]
+        o = gdo.oracle_extd2(lib, c["q"], c["t"], gdo.score_matrix(a, b), q, e, q2, e2, c["w"], c["zdrop"], c["end_bonus"], c["flag"])
+        for k in SCALARS:
+            assert o[k] == c[k], (k, o[k], c[k], c["preset"], c["w"], c["flag"])
+        assert np.array_equal(o["cigar"], c["cigar"])
+
+
+def test_extz2_oracle_matches_reference_golden(oracle):
+    gdo, lib = oracle
+    for c in load_ksw("ksw2_extz2"):
+        a, b, q, e, q2, e2 = gdo.PRESETS[c["preset"]]
+        o = gdo.oracle_extz2(lib, c["q"], c["t"], gdo.score_matrix(a, b), q, e, c["w"], c["zdrop"], c["end_bonus"], c["flag"])
+        for k in SCALARS:
+            assert o[k] == c[k], (k, o[k], c[k])
+        assert np.array_equal(o["cigar"], c["cigar"])
+
+
+def test_exact_match_oracle_matches_reference_golden(oracle):
+    gdo, lib = oracle
+    cases = load_exact()
+    assert any(e for _, _, e in cases) and any(not e for _, _, e in cases)
+    for q, t, expect in cases:
+        assert gdo.oracle_exact_match(lib, q, t) == expect
+
+
+def test_cigar_consumes_both_sequences(oracle):
+    """size-independent property: a reported global alignment consumes exactly qlen and tlen"""
+    gdo, lib = oracle
+    rng = np.random.default_rng(99)
+    for _ in range(60):
+        q, t = gdo.make_pair(rng, int(rng.integers(50, 900)), 0.02, 0.01, 0.01)
+        a, b, go, ge, go2, ge2 = gdo.PRESETS["hifi"]
+        o = gdo.oracle_extd2(lib, q, t, gdo.score_matrix(a, b), go, ge, go2, ge2, 200)
+        if o["score"] == gdo.NEG_INF:
+            assert len(o["cigar"]) == 0
+            continue
+        ops, lens = o["cigar"] & 0xf, o["cigar"] >> 4
+        assert lens[(ops == 0) | (ops == 1)].sum() == len(q)
+        assert lens[(ops == 0) | (ops == 2)].sum() == len(t)
+
+
+def test_self_alignment_is_all_match(oracle):
+    gdo, lib = oracle
+    rng = np.random.default_rng(5)
+    for n in (1, 15, 16, 17, 150, 1000):
+        t = rng.integers(0, 4, size=n, dtype=np.uint8)
+        a, b, go, ge, go2, ge2 = gdo.PRESETS["sr"]
+        o = gdo.oracle_extd2(lib, t, t, gdo.score_matrix(a, b), go, ge, go2, ge2, 150)
+        assert o["score"] == n * a and list(o["cigar"]) == [n << 4]
