@@ -151,11 +151,11 @@ static int gd_generic_cap(int qlen, int tlen, int w)
 static inline size_t gd_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // decide kernel + backtrace geometry of one alignment
-static void gd_plan_one(int mode, int qlen, int tlen, int w, int32_t &kind, int32_t &row_bytes)
+static void gd_plan_one(int mode, bool wave_scoring_ok, int qlen, int tlen, int w, int32_t &kind, int32_t &row_bytes)
 {
 	const int ncol = gd_ncol16(qlen, tlen, w);
 	kind = GD_KIND_GENERIC, row_bytes = ncol * 16;
-	if (mode == 1) return;
+	if (mode == 1 || !wave_scoring_ok) return;
 	if (gd_wave_supported(qlen, tlen, w, 64)) {
 		if (gd_wave_supported(qlen, tlen, w, 16)) kind = GD_KIND_WAVE16, row_bytes = 16 * 16;
 		else kind = GD_KIND_WAVE64, row_bytes = 64 * 16;
@@ -169,7 +169,7 @@ extern "C" size_t gdiet_hip_ksw_workspace_bytes(int n, const int64_t *qoff, cons
 		const int qlen = (int)(qoff[i + 1] - qoff[i]), tlen = (int)(toff[i + 1] - toff[i]);
 		if (qlen <= 0 || tlen <= 0) continue;
 		int32_t kind, rb;
-		gd_plan_one(0, qlen, tlen, w[i], kind, rb);
+		gd_plan_one(0, true, qlen, tlen, w[i], kind, rb);
 		const size_t a = (size_t)(qlen + tlen - 1) * (size_t)rb;
 		const size_t b = (size_t)(qlen + tlen - 1) * (size_t)gd_ncol16(qlen, tlen, w[i]) * 16; // forced-generic worst case
 		tot += gd_align256(std::max(a, b) + 64);
@@ -233,6 +233,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	GD_HIP(hipStreamSynchronize(stream));
 
 	ctx->h_tasks.resize(n);
+	const bool wave_scoring_ok = gd_wave_scoring_ok(K);
 	size_t bt = 0;
 	std::vector<int32_t> ids[3];
 	int max_cap = 0;
@@ -246,7 +247,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		T.exact_score = d_exact_score ? h_ex[i] : GD_NEG_INF;
 		T.pad = 0;
 		if (T.qlen <= 0 || T.tlen <= 0) { ctx->err = "empty sequence in batch (the reference returns without aligning)"; return GDIET_E_PARAM; }
-		gd_plan_one(ctx->kernel_mode, T.qlen, T.tlen, T.w, T.kind, T.row_bytes);
+		gd_plan_one(ctx->kernel_mode, wave_scoring_ok, T.qlen, T.tlen, T.w, T.kind, T.row_bytes);
 		if (ctx->kernel_mode == 2 && T.kind == GD_KIND_GENERIC) { ctx->err = "alignment does not fit the wave kernel"; return GDIET_E_PARAM; }
 		if (T.kind == GD_KIND_GENERIC) {
 			int cap = gd_generic_cap(T.qlen, T.tlen, T.w);

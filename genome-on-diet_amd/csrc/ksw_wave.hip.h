@@ -1,7 +1,117 @@
-// placeholder until the register-resident kernel lands (next commit)
+// K1 (register-resident form): one 64-lane wavefront per alignment, DP state in VGPRs, lane-to-lane dependency
+// through DPP wave_ror:1, two cells per packed 16-bit VALU instruction, 16 B of backtrace per lane per
+// anti-diagonal written with one coalesced global_store_dwordx4 (1 KiB per wavefront-row).
+// All arithmetic lives in ksw_wave_core.h (shared with the host lock-step emulator); this file is the row loop.
+//
+// Roofline note: per anti-diagonal a wavefront issues ~330 VALU instructions for 1024 cells and
+// stores 1024 B, i.e. ~1 B of HBM write per cell against ~20 lane-ops per cell: the kernel is VALU-issue bound
+// at roughly 0.6x of what the 8 TB/s HBM roofline would allow for the 1 B/cell backtrace.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ksw_common.h"
-static inline bool gd_wave_supported(int, int, int, int) { return false; }
-static inline void gd_launch_wave64(const KswTask *, const int32_t *, int, const uint8_t *, const uint8_t *, uint8_t *, int32_t *, int32_t *, KswConst, hipStream_t) {}
-static inline void gd_launch_wave16(const KswTask *, const int32_t *, int, const uint8_t *, const uint8_t *, uint8_t *, int32_t *, int32_t *, KswConst, hipStream_t) {}
+#include "ksw_wave_core.h"
+
+// lane l receives the value of lane l-1 (mod 64): DPP wave_ror:1 (GFX9 encoding 0x13C)
+__device__ __forceinline__ u32 gdw_ror1_wave(u32 v)
+{
+	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false);
+}
+
+static inline bool gd_wave_scoring_ok(const KswConst &C)
+{
+	WaveK K;
+	if (!gdw_make_consts(C, K)) return false;
+	// no 8-bit wrap-around anywhere in the reference recurrence for these magnitudes (see ksw_wave_core.h)
+	const int mis = C.sc_mis < 0 ? -C.sc_mis : C.sc_mis, n = C.sc_N < 0 ? -C.sc_N : C.sc_N;
+	return C.sc_mch > 0 && C.sc_mch + 2 * (C.q2 + C.e2) + (mis > n ? mis : n) + (C.q + C.e) <= 120;
+}
+
+static inline bool gd_wave_supported(int qlen, int tlen, int w, int lanes)
+{
+	if (lanes != 64) return false; // the 16-lane (4 alignments per wavefront) variant is not wired yet
+	return gd_wave_geometry_ok(qlen, tlen, w, lanes);
+}
+
+__global__ __launch_bounds__(256) void ksw_extd2_wave64_kernel(const KswTask *__restrict__ tasks,
+                                                               const int32_t *__restrict__ task_ids, int n_tasks,
+                                                               const uint8_t *__restrict__ qseq,
+                                                               const uint8_t *__restrict__ tseq,
+                                                               uint8_t *__restrict__ bt, int32_t *__restrict__ status,
+                                                               int32_t *__restrict__ score_out, WaveK K)
+{
+	constexpr int LANES = 64;
+	const int lane = threadIdx.x & 63;
+	const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+	if (slot >= n_tasks) return;
+	const int tid = __builtin_amdgcn_readfirstlane(task_ids[slot]);
+	if (__builtin_amdgcn_readfirstlane(status[tid]) != GD_ST_PENDING) return;
+	const KswTask *Tp = tasks + tid;
+	const int qlen = __builtin_amdgcn_readfirstlane(Tp->qlen), tlen = __builtin_amdgcn_readfirstlane(Tp->tlen);
+	int w = __builtin_amdgcn_readfirstlane(Tp->w);
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const uint8_t *query = qseq + Tp->qoff, *target = tseq + Tp->toff;
+	uint8_t *p = bt + Tp->bt_off + (size_t)lane * 16;
+	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+
+	WaveLane L;
+	gdw_load_block(L, K, lane, 0, query, qlen, target, tlen);
+	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
+	u32 qnext = 0;
+	for (int r = 0; r <= rend; ++r) {
+		WaveRow W;
+		W.r = r;
+		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+		const int advanced = W.st_ > prev_st_;
+		W.use_array = advanced;
+		W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
+		W.set_tr = (W.en0 | 15) >= r;
+		W.ukey = gdw_edge_key(K, r);
+		// (1) row r-1 values of the previous lane, fetched before any lane is touched
+		const u32 pX = gdw_ror1_wave(L.X[7]), pV = gdw_ror1_wave(L.V[7]), pX2 = gdw_ror1_wave(L.X2[7]);
+		// (2) query window advance; the lane whose block fell below the window takes over block +64
+		if (r > 0) gdw_shift_query(L, qnext);
+		if (advanced && L.blk < W.st_) gdw_load_block(L, K, L.blk + LANES, r, query, qlen, target, tlen);
+		qnext = gdw_qbyte(query, qlen, r + 1 - (L.blk << 4)); // prefetch for the next anti-diagonal
+		// (3) scalar fix-ups and the score row
+		if (W.set_tr) gdw_reset_tr(L, K, W);
+		if (W.st0 != prev_st0 || W.up != prev_up || advanced) gdw_make_sel(L, W.st0, W.up);
+		gdw_update_scores(L, K);
+		// (4) DP cells of the lanes inside the reference's 16-aligned window
+		if (L.blk <= W.en_) {
+			u32 out[4];
+			gdw_compute(L, K, W, pX, pV, pX2, out);
+			*reinterpret_cast<uint4 *>(p + (size_t)r * (LANES * 16)) = make_uint4(out[0], out[1], out[2], out[3]);
+		}
+		// (5) score trackers
+		if (r == 0) L.R = gdw_lo(L.V[0]) - K.B1 - K.qe8;
+		else L.R += gdw_lo(L.V[0]) - K.B1;
+		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 15) == 0) {
+			const int h = (int)gdw_ror1_wave((u32)gdw_track_handoff(L));
+			if (L.blk == W.en_) L.R = h + gdw_lo(L.U[0]);
+		}
+		if (W.en0 == tlen - 1) {
+			if (L.blk == mlast) {
+				if (!have_f) Rf = gdw_track_to_slot(L, sl);
+				else Rf += gdw_cell(L.V, sl) - K.B1;
+			}
+			have_f = 1;
+		}
+		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
+	}
+	if (L.blk == mlast) {
+		score_out[tid] = Rf >> 3;
+		status[tid] = GD_ST_DONE;
+	}
+}
+
+static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
+                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s)
+{
+	WaveK K;
+	gdw_make_consts(C, K);
+	hipLaunchKernelGGL(ksw_extd2_wave64_kernel, dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+}
+static inline void gd_launch_wave16(const KswTask *, const int32_t *, int, const uint8_t *, const uint8_t *, uint8_t *,
+                                    int32_t *, int32_t *, KswConst, hipStream_t) {}

@@ -1,0 +1,321 @@
+// K1 (register-resident form): the per-lane arithmetic of the wavefront ksw_extd2 kernel, written once for the
+// device kernel (ksw_wave.hip.h) and for the host lock-step emulator used by tests/test_wave_emulator.py.
+//
+// Mapping (HiFi geometry, w = 1000): one 64-lane wavefront per alignment.  The reference's 16-lane SSE block
+// [16m, 16m+15] of target positions is ONE GPU lane; lane = m mod 64, so the 64 lanes always hold the 64
+// consecutive blocks [st_, st_+63] that can be touched by an anti-diagonal (n_col_ <= 64).  A lane therefore is
+// either wholly inside the reference's 16-aligned computed window [st, en] or wholly outside it, which makes the
+// reference's padding-cell behaviour (SURVEY Notes K1.1-K1.3) fall out of plain lane predication.
+//
+// Per lane the 16 cells are held as 8 packed registers per state array: register k = (cell k | cell k+8 << 16),
+// so "row r-1, cell t-1" is register k-1 (no instruction) except for k = 0, which takes one DPP rotate from the
+// previous lane plus one v_alignbit.  Arithmetic is packed 16-bit (v_pk_add/sub/max/min_i16): two cells per VALU
+// instruction.  Values are kept as KEYS  8*value + tie + bias:
+//     U,V: 8u+B1, 8v+B1      X: 8x+3+B1   Y: 8y+2+B1   X2: 8x2+1+B1   Y2: 8y2+B1      S: 8s+4+2*B1
+//     B1 = 8*(q+e-1)
+//   * a = X+V, b = Y+U, a2 = X2+V, b2 = Y2+U then all carry bias 2*B1 and tie codes 3,2,1,0 (S: 4), so ONE chain
+//     of four packed max gives both z (key & ~7) and the reference's direction d = 4 - (key & 7): the strict-'>'
+//     priority order z,a,b,a2,b2 of SR/ksw2_extd2_sse.c:235-242 is "largest value, then largest tie code".
+//   * with B1 = 8(q+e-1) the no-continuation value x = -(q+e) is key -5 (y: -6) and every continuation value is
+//     >= 0, so the E/F continuation flags (:263,:266) are the sign bits of the stored X/Y registers.
+// 8-bit wrap-around of the reference cannot occur for parameters accepted by gd_wave_supported() (all keys stay
+// far inside int16), so 16-bit arithmetic reproduces the int8 results exactly; the emulator test and the GPU
+// parity tests check that against the oracle.
+//
+// The score (approximate-max walk, :367-383) is obtained from the identity H(r,t)-H(r-1,t) = v(r,t),
+// H(r,t+1)-H(r,t) = u(r,t+1)-v(r,t): the sum along ANY monotone in-band path from (0,0) to the last cell equals
+// the reference's H0 (each unit square between two such paths contributes u+v'=v+u' identically, because both
+// u(r,t) and v(r,t) are z minus the stored neighbours).  Each lane tracks 8*H at its cell 0; see gdw_track_*.
+#pragma once
+#include <stdint.h>
+#include "ksw_common.h"
+
+#if defined(__HIPCC__)
+#define GDW_HD __host__ __device__ __forceinline__
+#else
+#define GDW_HD static inline
+#endif
+
+typedef uint32_t u32;
+
+// ---- packed 16-bit helpers ---------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef short gdw_v2s __attribute__((ext_vector_type(2)));
+GDW_HD gdw_v2s gdw_as_v(u32 a) { return __builtin_bit_cast(gdw_v2s, a); }
+GDW_HD u32 gdw_as_u(gdw_v2s a) { return __builtin_bit_cast(u32, a); }
+GDW_HD u32 pk_add(u32 a, u32 b) { return gdw_as_u(gdw_as_v(a) + gdw_as_v(b)); }
+GDW_HD u32 pk_sub(u32 a, u32 b) { return gdw_as_u(gdw_as_v(a) - gdw_as_v(b)); }
+GDW_HD u32 pk_max(u32 a, u32 b) { return gdw_as_u(__builtin_elementwise_max(gdw_as_v(a), gdw_as_v(b))); }
+GDW_HD u32 pk_min(u32 a, u32 b) { return gdw_as_u(__builtin_elementwise_min(gdw_as_v(a), gdw_as_v(b))); }
+GDW_HD u32 gdw_perm(u32 s0, u32 s1, u32 sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+GDW_HD u32 gdw_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+GDW_HD u32 gdw_alignbyte(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+#else
+GDW_HD u32 pk_add(u32 a, u32 b) { return ((a + b) & 0xffffu) | ((((a >> 16) + (b >> 16)) & 0xffffu) << 16); }
+GDW_HD u32 pk_sub(u32 a, u32 b) { return ((a - b) & 0xffffu) | ((((a >> 16) - (b >> 16)) & 0xffffu) << 16); }
+GDW_HD u32 pk_max(u32 a, u32 b)
+{
+	int16_t al = (int16_t)a, bl = (int16_t)b, ah = (int16_t)(a >> 16), bh = (int16_t)(b >> 16);
+	return (u32)(uint16_t)(al > bl ? al : bl) | (u32)(uint16_t)(ah > bh ? ah : bh) << 16;
+}
+GDW_HD u32 pk_min(u32 a, u32 b)
+{
+	int16_t al = (int16_t)a, bl = (int16_t)b, ah = (int16_t)(a >> 16), bh = (int16_t)(b >> 16);
+	return (u32)(uint16_t)(al < bl ? al : bl) | (u32)(uint16_t)(ah < bh ? ah : bh) << 16;
+}
+GDW_HD u32 gdw_perm(u32 s0, u32 s1, u32 sel) // v_perm_b32: bytes 0-3 = s1, 4-7 = s0, 12 -> 0x00, >= 13 -> 0xff
+{
+	uint64_t src = (uint64_t)s0 << 32 | s1;
+	u32 out = 0;
+	for (int i = 0; i < 4; ++i) {
+		u32 s = (sel >> (8 * i)) & 0xff, b;
+		if (s <= 7) b = (u32)(src >> (8 * s)) & 0xff;
+		else if (s == 12) b = 0;
+		else if (s >= 13) b = 0xff;
+		else b = ((src >> (16 * (s - 8) + 15)) & 1) ? 0xff : 0; // 8..11: sign of bytes 1,3,5,7 (unused here)
+		out |= b << (8 * i);
+	}
+	return out;
+}
+GDW_HD u32 gdw_alignbit(u32 hi, u32 lo, u32 sh) { return (u32)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+GDW_HD u32 gdw_alignbyte(u32 hi, u32 lo, u32 sh) { return (u32)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3))); }
+#endif
+GDW_HD u32 gdw_bfi(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
+GDW_HD u32 gdw_pack2(int v) { return ((u32)v & 0xffffu) | ((u32)v << 16); }
+GDW_HD int gdw_lo(u32 a) { return (int)(int16_t)(a & 0xffffu); }
+GDW_HD int gdw_hi(u32 a) { return (int)(int16_t)(a >> 16); }
+
+// ---- uniform constants -------------------------------------------------------------------------------------
+struct WaveK {
+	int32_t B1;                // 8*(q+e-1)
+	u32 cx, cy, cx2, cy2;      // packed no-continuation / initial keys of X, Y, X2, Y2
+	u32 uv0;                   // packed initial key of U and V (value -(q+e))
+	u32 zmax;                  // packed 8*sc_mch + 2*B1
+	u32 te, te2;               // packed: tE = z8 - te (te = 8(q-1)); tE2 = z8 - te2 (te2 = B1 - 8*e2)
+	u32 w2x, w2y;              // packed cx2+1, cy2+1
+	u32 lut_lo, lut_hi;        // S-key bytes indexed by (T^Q)|TN: [match,mis,mis,mis] / [N,N,N,N]
+	u32 s0;                    // S-key byte of score 0, replicated (the reference's zero-filled s[])
+	int32_t key_open, key_e, key_ld, key_e2; // boundary keys of v1 / u[r]: -(q+e), -e, long_diff, -e2 (SR/ksw2_extd2_sse.c:158,162)
+	int32_t long_thres;
+	int32_t qe8;               // 8*(q+e)
+};
+
+static inline bool gdw_make_consts(const KswConst &C, WaveK &K)
+{
+	const int qe = C.q + C.e, qe2 = C.q2 + C.e2;
+	K.B1 = 8 * (qe - 1);
+	if (qe < 1) return false;
+	K.cx = gdw_pack2(8 * -qe + 3 + K.B1), K.cy = gdw_pack2(8 * -qe + 2 + K.B1);
+	K.cx2 = gdw_pack2(8 * -qe2 + 1 + K.B1), K.cy2 = gdw_pack2(8 * -qe2 + K.B1);
+	K.uv0 = gdw_pack2(8 * -qe + K.B1);
+	K.zmax = gdw_pack2(8 * C.sc_mch + 2 * K.B1);
+	K.te = gdw_pack2(8 * (C.q - 1)), K.te2 = gdw_pack2(K.B1 - 8 * C.e2);
+	K.w2x = gdw_pack2(8 * -qe2 + 1 + K.B1 + 1), K.w2y = gdw_pack2(8 * -qe2 + K.B1 + 1);
+	const int km = 8 * C.sc_mch + 4 + 2 * K.B1, kx = 8 * C.sc_mis + 4 + 2 * K.B1, kn = 8 * C.sc_N + 4 + 2 * K.B1, k0 = 4 + 2 * K.B1;
+	if (km < 0 || km > 255 || kx < 0 || kx > 255 || kn < 0 || kn > 255 || k0 > 255) return false; // S keys must fit a byte
+	K.lut_lo = (u32)km | (u32)kx << 8 | (u32)kx << 16 | (u32)kx << 24;
+	K.lut_hi = (u32)kn * 0x01010101u;
+	K.s0 = (u32)k0 * 0x01010101u;
+	K.key_open = 8 * -qe + K.B1, K.key_e = 8 * -C.e + K.B1, K.key_ld = 8 * C.long_diff + K.B1, K.key_e2 = 8 * -C.e2 + K.B1;
+	K.long_thres = C.long_thres;
+	K.qe8 = 8 * qe;
+	// every key must stay well inside int16: |value| <= 127 => |key| <= 8*127 + 7 + 2*B1
+	if (8 * 127 + 7 + 2 * K.B1 > 30000) return false;
+	return true;
+}
+
+// boundary key of v1 (st == 0) and of u[r] (SR/ksw2_extd2_sse.c:158,162)
+GDW_HD int gdw_edge_key(const WaveK &K, int r)
+{
+	return r == 0 ? K.key_open : r < K.long_thres ? K.key_e : r == K.long_thres ? K.key_ld : K.key_e2;
+}
+
+// ---- per-lane state ----------------------------------------------------------------------------------------
+struct WaveLane {
+	u32 U[8], V[8], X[8], Y[8], X2[8], Y2[8]; // packed keys, register k = cells (k, k+8) of the lane's block
+	u32 Sb[4];   // S-key bytes, dword g = cells 4g..4g+3 (persistent: stale cells keep their old score)
+	u32 Tb[4];   // target nt4 bytes of the block (0 beyond tlen)
+	u32 TN[4];   // 0x04 where the target byte is N
+	u32 Qc[4];   // query nt4 bytes facing the cells on the current anti-diagonal: cell i <-> query[r - (tb+i)]
+	u32 SEL[4];  // v_perm selectors blending fresh scores into Sb (per byte: 4+i = take fresh, i = keep)
+	int32_t blk; // block index m held by the lane (m mod lanes == lane id)
+	int32_t R;   // 8*H(r, 16m): score tracker at cell 0 of the block
+};
+
+// query byte facing cell t on anti-diagonal r; outside [0,qlen) the reference reads zeroed memory
+GDW_HD u32 gdw_qbyte(const uint8_t *query, int qlen, int j) { return (j >= 0 && j < qlen) ? query[j] : 0u; }
+
+// (re)load a lane for block m at anti-diagonal r: reference's initial fill (SR/ksw2_extd2_sse.c:107,111-116)
+GDW_HD void gdw_load_block(WaveLane &L, const WaveK &K, int m, int r, const uint8_t *query, int qlen,
+                           const uint8_t *target, int tlen)
+{
+	L.blk = m;
+	const int tb = m << 4;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) L.U[k] = K.uv0, L.V[k] = K.uv0, L.X[k] = K.cx, L.Y[k] = K.cy, L.X2[k] = K.cx2, L.Y2[k] = K.cy2;
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		u32 tw = 0, qw = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int t = tb + 4 * g + b;
+			tw |= (t < tlen ? (u32)target[t] : 0u) << (8 * b);
+			qw |= gdw_qbyte(query, qlen, r - t) << (8 * b);
+		}
+		L.Tb[g] = tw, L.TN[g] = tw & 0x04040404u, L.Qc[g] = qw, L.Sb[g] = K.s0, L.SEL[g] = 0x03020100u;
+	}
+	L.R = 0;
+}
+
+// uniform description of one anti-diagonal
+struct WaveRow {
+	int r, st0, en0, st_, en_, up;
+	int use_array;   // boundary x1/x21/v1 come from the previous lane's row r-1 values (block st_-1 just retired)
+	int v1key;       // otherwise: key of v1 (x1/x21 are always the no-continuation keys then)
+	int set_tr;      // en >= r: cell t == r gets u/y/y2 reset (:160-163)
+	int ukey;        // key of u[r] for that reset
+};
+
+// selectors for the score blend of one lane: cells [st0, up) are rewritten (:166-180)
+GDW_HD void gdw_make_sel(WaveLane &L, int st0, int up)
+{
+	const int tb = L.blk << 4;
+	int lo = st0 - tb, hi = up - tb;
+	lo = lo < 0 ? 0 : lo > 16 ? 16 : lo;
+	hi = hi < 0 ? 0 : hi > 16 ? 16 : hi;
+	const u32 bm = hi > lo ? (((1u << (hi - lo)) - 1u) << lo) : 0u; // bit i: cell i is rewritten
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		const u32 n = (bm >> (4 * g)) & 15u;
+		const u32 spread = (n * 0x00204081u) & 0x01010101u; // bit i of n -> bit 0 of byte i
+		L.SEL[g] = 0x03020100u + (spread << 2);
+	}
+}
+
+// advance the query window by one anti-diagonal: cell i now faces what cell i-1 faced; cell 0 gets `inc`
+GDW_HD void gdw_shift_query(WaveLane &L, u32 inc)
+{
+	L.Qc[3] = gdw_alignbyte(L.Qc[3], L.Qc[2], 3);
+	L.Qc[2] = gdw_alignbyte(L.Qc[2], L.Qc[1], 3);
+	L.Qc[1] = gdw_alignbyte(L.Qc[1], L.Qc[0], 3);
+	L.Qc[0] = (L.Qc[0] << 8) | (inc & 0xffu);
+}
+
+// rewrite the persistent score bytes of this lane (every lane, active or not: the rewritten range may spill into
+// the first block above the computed window)
+GDW_HD void gdw_update_scores(WaveLane &L, const WaveK &K)
+{
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		const u32 x = (L.Tb[g] ^ L.Qc[g]) | L.TN[g];     // 0 match, 1-3 mismatch, 4-7 ambiguous (query N = 4)
+		const u32 fresh = gdw_perm(K.lut_hi, K.lut_lo, x);
+		L.Sb[g] = gdw_perm(fresh, L.Sb[g], L.SEL[g]);
+	}
+}
+
+// reset of cell t == r (u, y, y2), only while en >= r (:160-163)
+GDW_HD void gdw_reset_tr(WaveLane &L, const WaveK &K, const WaveRow &W)
+{
+	if (L.blk != (W.r >> 4)) return;
+	const int k = W.r & 7;
+	const u32 mask = (W.r & 8) ? 0xffff0000u : 0x0000ffffu;
+	const u32 uk = gdw_pack2(W.ukey);
+#pragma unroll
+	for (int kk = 0; kk < 8; ++kk)
+		if (kk == k) {
+			L.U[kk] = gdw_bfi(mask, uk, L.U[kk]);
+			L.Y[kk] = gdw_bfi(mask, K.cy, L.Y[kk]);
+			L.Y2[kk] = gdw_bfi(mask, K.cy2, L.Y2[kk]);
+		}
+}
+
+// One anti-diagonal for one ACTIVE lane.  pX/pV/pX2: register 7 of X/V/X2 of the previous lane (row r-1 values).
+// bt: the lane's 16 backtrace bytes of this row (4 dwords; byte 4g+h = cell 2g+(h&1)+8*(h>>1)).
+// backtrace byte = (4 - d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6, n* = "no continuation" (inverse of :263-272)
+GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u32 pV, u32 pX2, u32 bt[4])
+{
+	u32 inX = gdw_alignbit(L.X[7], pX, 16), inV = gdw_alignbit(L.V[7], pV, 16), inX2 = gdw_alignbit(L.X2[7], pX2, 16);
+	if (L.blk == W.st_ && !W.use_array) { // first computed block: boundary scalars x1, v1, x21 (:149-159)
+		inX = (inX & 0xffff0000u) | (K.cx & 0xffffu);
+		inV = (inV & 0xffff0000u) | ((u32)W.v1key & 0xffffu);
+		inX2 = (inX2 & 0xffff0000u) | (K.cx2 & 0xffffu);
+	}
+	u32 B[8];
+#pragma unroll
+	for (int k = 7; k >= 0; --k) {
+		const u32 xin = k ? L.X[k - 1] : inX, vin = k ? L.V[k - 1] : inV, x2in = k ? L.X2[k - 1] : inX2;
+		const u32 sk = gdw_perm(L.Sb[2 + (k >> 2)], L.Sb[k >> 2], 0x0c000c00u | (u32)(k & 3) | (u32)(4 + (k & 3)) << 16);
+		const u32 a = pk_add(xin, vin), b = pk_add(L.Y[k], L.U[k]), a2 = pk_add(x2in, vin), b2 = pk_add(L.Y2[k], L.U[k]);
+		const u32 zk = pk_max(pk_max(pk_max(pk_max(sk, a), b), a2), b2);
+		const u32 dlow = zk & 0x00070007u;
+		const u32 z8 = pk_min(zk & 0xfff8fff8u, K.zmax);
+		const u32 nU = pk_sub(z8, vin), nV = pk_sub(z8, L.U[k]);
+		const u32 tE = pk_sub(z8, K.te), tE2 = pk_sub(z8, K.te2);
+		const u32 nX = pk_max(pk_sub(a, tE), K.cx), nY = pk_max(pk_sub(b, tE), K.cy);
+		const u32 nX2 = pk_max(pk_sub(a2, tE2), K.cx2), nY2 = pk_max(pk_sub(b2, tE2), K.cy2);
+		const u32 wX2 = pk_sub(nX2, K.w2x), wY2 = pk_sub(nY2, K.w2y); // negative <=> no continuation
+		const u32 g1 = gdw_bfi(0x80008000u, nX, nY >> 1);
+		const u32 g2 = gdw_bfi(0x80008000u, wX2, wY2 >> 1);
+		const u32 g = gdw_bfi(0xc000c000u, g1, g2 >> 2);
+		B[k] = ((g >> 9) & 0x00780078u) | dlow;
+		L.U[k] = nU, L.V[k] = nV, L.X[k] = nX, L.Y[k] = nY, L.X2[k] = nX2, L.Y2[k] = nY2;
+	}
+#pragma unroll
+	for (int g = 0; g < 4; ++g) bt[g] = B[2 * g] | (B[2 * g + 1] << 8);
+}
+
+// ---- score tracking ----------------------------------------------------------------------------------------
+// sum of the 16 V keys / of the U keys of cells 1..15 of a lane (horizontal step across a block)
+GDW_HD int gdw_sum16(const u32 A[8])
+{
+	u32 s = pk_add(pk_add(pk_add(A[0], A[1]), pk_add(A[2], A[3])), pk_add(pk_add(A[4], A[5]), pk_add(A[6], A[7])));
+	return gdw_lo(s) + gdw_hi(s);
+}
+// what the predecessor lane contributes to the tracker of the block activated above it on this anti-diagonal:
+//   8*H(r,16m) = 8*H(r,16(m-1)) + sum_{i=1..15} U_i - sum_{i=0..15} V_i  [+ U_0 of the new block, added there]
+GDW_HD int gdw_track_handoff(const WaveLane &L) { return L.R + gdw_sum16(L.U) - gdw_lo(L.U[0]) - gdw_sum16(L.V); }
+
+// key of cell `slot` (0..15) of a packed array
+GDW_HD int gdw_cell(const u32 A[8], int slot)
+{
+	u32 v = 0;
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		if (k == (slot & 7)) v = A[k];
+	return (slot & 8) ? gdw_hi(v) : gdw_lo(v);
+}
+// 8*H(r, 16m+sl) from 8*H(r,16m): partial horizontal walk inside one block
+GDW_HD int gdw_track_to_slot(const WaveLane &L, int sl)
+{
+	int acc = L.R;
+	for (int i = 0; i < sl; ++i) acc += gdw_cell(L.U, i + 1) - gdw_cell(L.V, i);
+	return acc;
+}
+
+// ---- host-side admission test --------------------------------------------------------------------------------
+// The wave kernel takes an alignment iff (a) every anti-diagonal fits `lanes` blocks incl. the score-row spill,
+// (b) the band never empties, (c) each block's tracker can be seeded from the block below when it enters the band
+// and the final cell can be reached from cell 0 of the last block (the band must be >= 17 cells wide there).
+static inline bool gd_wave_geometry_ok(int qlen, int tlen, int w, int lanes)
+{
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	if (qlen < 1 || tlen < 1) return false;
+	if (gd_ncol16(qlen, tlen, w) > lanes) return false;
+	// (b): for w >= 1 the band of every anti-diagonal is non-empty iff the corner is inside the band
+	if (w < 1 || tlen - qlen > w || qlen - tlen > w) return false;
+	// (c)
+	const int mlast = (tlen - 1) >> 4;
+	for (int m = 1; m <= mlast; ++m) {
+		int rs = 16 * m > 32 * m - w ? 16 * m : 32 * m - w; // first anti-diagonal with en0 >= 16m
+		int s0, e0;
+		gd_band(rs, qlen, tlen, w, s0, e0);
+		if (e0 != 16 * m || s0 > 16 * (m - 1)) return false;
+	}
+	{
+		int rb = tlen - 1 > 2 * (tlen - 1) - w ? tlen - 1 : 2 * (tlen - 1) - w; // first anti-diagonal with en0 == tlen-1
+		int s0, e0;
+		gd_band(rb, qlen, tlen, w, s0, e0);
+		if (e0 != tlen - 1 || s0 > 16 * mlast) return false;
+	}
+	return true;
+}

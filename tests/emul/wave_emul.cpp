@@ -1,0 +1,182 @@
+// Host lock-step emulator of the register-resident ksw_extd2 wavefront kernel (test infrastructure).
+// It drives genome-on-diet_amd/csrc/ksw_wave_core.h -- the very per-lane code the GPU kernel compiles -- with 64
+// (or 16) emulated lanes, exchanging registers between lanes where the GPU uses DPP, and compares score and CIGAR
+// with the CPU oracle (oracle/gdo_ksw2.c) on seeded random pairs.  Exit code 0 = all pairs identical.
+//
+//   g++ -O2 -I genome-on-diet_amd/csrc -I oracle tests/emul/wave_emul.cpp oracle/gdo_ksw2.c -o wave_emul
+//   ./wave_emul <seed> <n_pairs> <lanes>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <random>
+#define __host__
+#define __device__
+#include "ksw_wave_core.h"
+#include "gdo_ksw2.h"
+
+struct EmuResult { int score; std::vector<uint32_t> cigar; };
+
+// lock-step emulation of ksw_extd2_wave_kernel<LANES>; mirrors the device row loop statement by statement
+static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_t *target, int tlen, int w, const KswConst &C)
+{
+	WaveK K;
+	if (!gdw_make_consts(C, K)) { fprintf(stderr, "consts rejected\n"); exit(2); }
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+	std::vector<WaveLane> L(LANES);
+	std::vector<uint8_t> bt((size_t)(rend + 1) * LANES * 16, 0xEE);
+	for (int l = 0; l < LANES; ++l) gdw_load_block(L[l], K, l, 0, query, qlen, target, tlen);
+	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
+	for (int r = 0; r <= rend; ++r) {
+		WaveRow W;
+		W.r = r;
+		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		if (W.st0 > W.en0) { fprintf(stderr, "empty band in wave kernel\n"); exit(2); }
+		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+		const int advanced = W.st_ > prev_st_;
+		W.use_array = advanced;
+		W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
+		W.set_tr = (W.en0 | 15) >= r;
+		W.ukey = gdw_edge_key(K, r);
+		// (1) cross-lane exchange of row r-1 values (DPP wave_ror:1 on the GPU), before anything is modified
+		std::vector<u32> pX(LANES), pV(LANES), pX2(LANES);
+		for (int l = 0; l < LANES; ++l) {
+			const int p = (l + LANES - 1) % LANES;
+			pX[l] = L[p].X[7], pV[l] = L[p].V[7], pX2[l] = L[p].X2[7];
+		}
+		// (2) query window advance / block retirement
+		int reloaded = 0;
+		for (int l = 0; l < LANES; ++l) {
+			if (r > 0) gdw_shift_query(L[l], gdw_qbyte(query, qlen, r - (L[l].blk << 4)));
+			if (L[l].blk < W.st_) gdw_load_block(L[l], K, L[l].blk + LANES, r, query, qlen, target, tlen), reloaded = 1;
+		}
+		// (3) per-row scalar fix-ups and the score row
+		const int remask = W.st0 != prev_st0 || W.up != prev_up || reloaded;
+		for (int l = 0; l < LANES; ++l) {
+			if (W.set_tr) gdw_reset_tr(L[l], K, W);
+			if (remask) gdw_make_sel(L[l], W.st0, W.up);
+			gdw_update_scores(L[l], K);
+		}
+		// (4) the DP cells of the active lanes
+		for (int l = 0; l < LANES; ++l)
+			if (L[l].blk <= W.en_) {
+				u32 out[4];
+				gdw_compute(L[l], K, W, pX[l], pV[l], pX2[l], out);
+				memcpy(&bt[((size_t)r * LANES + l) * 16], out, 16);
+			}
+		// (5) score trackers
+		if (r == 0) L[0].R = gdw_lo(L[0].V[0]) - K.B1 - K.qe8;
+		else for (int l = 0; l < LANES; ++l) L[l].R += gdw_lo(L[l].V[0]) - K.B1;
+		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 15) == 0) {
+			const int m = W.en0 >> 4;
+			const int h = gdw_track_handoff(L[(m - 1) % LANES]);
+			L[m % LANES].R = h + gdw_lo(L[m % LANES].U[0]);
+		}
+		if (W.en0 == tlen - 1) {
+			WaveLane &F = L[mlast % LANES];
+			if (!have_f) Rf = gdw_track_to_slot(F, sl), have_f = 1;
+			else Rf += gdw_cell(F.V, sl) - K.B1;
+		}
+		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
+	}
+	EmuResult res;
+	if (Rf % 8) { fprintf(stderr, "tracker not a multiple of 8\n"); exit(2); }
+	res.score = Rf / 8;
+	// backtrack: convert the wave layout to the reference layout and run the oracle's backtrack on it
+	const int ncol = gd_ncol16(qlen, tlen, w);
+	std::vector<uint8_t> p((size_t)(rend + 1) * ncol * 16 + 16, 0);
+	std::vector<int> off(2 * (rend + 1));
+	for (int r = 0; r <= rend; ++r) {
+		int st0, en0;
+		gd_band(r, qlen, tlen, w, st0, en0);
+		const int st = st0 & ~15, en = en0 | 15;
+		off[r] = st, off[rend + 1 + r] = en;
+		for (int i = st; i <= en; ++i) {
+			const int c = i & 15, g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
+			const uint8_t b = bt[((size_t)r * LANES + ((i >> 4) % LANES)) * 16 + 4 * g + h];
+			const uint8_t ref = (uint8_t)((4 - (b & 7)) | (((b >> 6) & 1) ? 0 : 0x08) | (((b >> 5) & 1) ? 0 : 0x10) |
+			                              (((b >> 4) & 1) ? 0 : 0x20) | (((b >> 3) & 1) ? 0 : 0x40));
+			p[(size_t)r * ncol * 16 + (i - st)] = ref;
+		}
+	}
+	int m_cigar = 0, n_cigar = 0;
+	uint32_t *cigar = 0;
+	gdo_backtrack(0, 0, p.data(), off.data(), off.data() + rend + 1, ncol * 16, tlen - 1, qlen - 1, &m_cigar, &n_cigar, &cigar);
+	res.cigar.assign(cigar, cigar + n_cigar);
+	free(cigar);
+	return res;
+}
+
+static void mutate(std::mt19937 &g, const std::vector<uint8_t> &t, std::vector<uint8_t> &q, double sub, double ins, double del, double nfrac)
+{
+	std::uniform_real_distribution<double> U(0, 1);
+	q.clear();
+	for (uint8_t c : t) {
+		double r = U(g);
+		if (r < del) continue;
+		if (r < del + ins) q.push_back(g() & 3);
+		if (U(g) < sub) c = (c + 1 + g() % 3) & 3;
+		if (U(g) < nfrac) c = 4;
+		q.push_back(c);
+	}
+	if (q.empty()) q.push_back(0);
+}
+
+int main(int argc, char **argv)
+{
+	const unsigned seed = argc > 1 ? atoi(argv[1]) : 1;
+	const int n = argc > 2 ? atoi(argv[2]) : 200, LANES = argc > 3 ? atoi(argv[3]) : 64;
+	std::mt19937 g(seed);
+	const int presets[3][6] = {{2, 8, 12, 2, 24, 1}, {1, 4, 6, 2, 26, 1}, {2, 4, 4, 2, 24, 1}};
+	int n_run = 0, n_bad = 0, n_skip = 0;
+	for (int it = 0; it < n; ++it) {
+		const int *P = presets[it % 3];
+		int tlen, w;
+		double sub = 0.01, ins = 0.003, del = 0.003, nfrac = (it % 7 == 0) ? 0.02 : 0.0;
+		if (LANES == 16) tlen = 100 + g() % 120, w = 32 + g() % 130;
+		else {
+			switch (it % 5) {
+			case 0: tlen = 150, w = 150; break;
+			case 1: tlen = 300 + g() % 2500, w = 40 + g() % 400; break;
+			case 2: tlen = 1200 + g() % 1800, w = 1000; break;
+			case 3: tlen = 64 + g() % 400, w = 32 + g() % 100, sub = 0.05, ins = 0.03, del = 0.03; break;
+			default: tlen = 500 + g() % 1500, w = 17 + g() % 985, sub = 0.03, ins = 0.02, del = 0.02; break;
+			}
+		}
+		std::vector<uint8_t> t(tlen), q;
+		for (auto &c : t) c = g() & 3;
+		if (nfrac > 0) for (auto &c : t) if ((g() % 1000) < 20) c = 4;
+		mutate(g, t, q, sub, ins, del, nfrac);
+		if (it % 11 == 3 && (int)q.size() > 200) { // a long indel near the band edge
+			int sz = (int)(w * 0.45), pos = 50 + g() % (q.size() - 100);
+			if (it & 1) q.insert(q.begin() + pos, sz, (uint8_t)(g() & 3));
+			else if (pos + sz < (int)q.size()) q.erase(q.begin() + pos, q.begin() + pos + sz);
+		}
+		const int qlen = (int)q.size();
+		KswConst C;
+		C.q = P[2], C.e = P[3], C.q2 = P[4], C.e2 = P[5];
+		if (C.q2 + C.e2 < C.q + C.e) std::swap(C.q, C.q2), std::swap(C.e, C.e2);
+		C.sc_mch = P[0], C.sc_mis = -P[1], C.sc_N = -C.e2;
+		C.long_thres = C.e != C.e2 ? (C.q2 - C.q) / (C.e - C.e2) - 1 : 0;
+		if (C.q2 + C.e2 + C.long_thres * C.e2 > C.q + C.e + C.long_thres * C.e) ++C.long_thres;
+		C.long_diff = C.long_thres * (C.e - C.e2) - (C.q2 - C.q) - C.e2;
+		if (!gd_wave_geometry_ok(qlen, tlen, w, LANES)) { ++n_skip; continue; }
+		int8_t mat[25];
+		for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? P[0] : -P[1]);
+		gdo_extz_t ez;
+		memset(&ez, 0, sizeof(ez));
+		gdo_ksw_extd2(qlen, q.data(), tlen, t.data(), 5, mat, P[2], P[3], P[4], P[5], w, -1, 0, GDO_EZ_APPROX_MAX, &ez);
+		EmuResult e = emulate(LANES, q.data(), qlen, t.data(), tlen, w, C);
+		++n_run;
+		bool ok = e.score == ez.score && (int)e.cigar.size() == ez.n_cigar && (ez.n_cigar == 0 || !memcmp(e.cigar.data(), ez.cigar, 4 * ez.n_cigar));
+		if (!ok) {
+			++n_bad;
+			if (n_bad <= 10) fprintf(stderr, "MISMATCH it=%d qlen=%d tlen=%d w=%d preset=%d score emu=%d oracle=%d ncig %zu/%d\n", it, qlen, tlen, w, it % 3, e.score, ez.score, e.cigar.size(), ez.n_cigar);
+		}
+		free(ez.cigar);
+	}
+	printf("wave_emul lanes=%d pairs_run=%d skipped=%d mismatches=%d\n", LANES, n_run, n_skip, n_bad);
+	return n_bad ? 1 : (n_run ? 0 : 3);
+}

@@ -1,0 +1,23 @@
+"""CPU: the per-lane code of the register-resident HIP kernel (genome-on-diet_amd/csrc/ksw_wave_core.h), driven by a
+host lock-step emulator, reproduces the oracle's score and CIGAR bit for bit on seeded random pairs."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def emul(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("emul") / "wave_emul")
+    subprocess.check_call(["g++", "-O2", "-w", "-I", os.path.join(ROOT, "genome-on-diet_amd", "csrc"), "-I", os.path.join(ROOT, "oracle"),
+                           os.path.join(ROOT, "tests", "emul", "wave_emul.cpp"), "-x", "c", os.path.join(ROOT, "oracle", "gdo_ksw2.c"), "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("seed,lanes", [(1, 64), (2, 64), (3, 16)])
+def test_wave_core_matches_oracle(emul, seed, lanes):
+    out = subprocess.run([emul, str(seed), "400", str(lanes)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout
