@@ -83,7 +83,13 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 		int force_state = -1;
 		if (i < off) force_state = 2;
 		if (i > off_end) force_state = 1;
-		const uint32_t tmp = force_state < 0 ? p[gd_bt_index(T, r, i, off)] : 0;
+		uint32_t tmp = force_state < 0 ? p[gd_bt_index(T, r, i, off)] : 0;
+		if (force_state < 0 && T.kind != GD_KIND_GENERIC) {
+			// wave kernels store (4-d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6 with n* = "no continuation"; rebuild the
+			// reference's byte d | cX<<3 | cY<<4 | cX2<<5 | cY2<<6 (SR/ksw2.h:127-130)
+			const uint32_t nb = ~tmp;
+			tmp = (4u - (tmp & 7u)) | ((nb >> 3) & 0x08u) | ((nb >> 1) & 0x10u) | ((nb << 1) & 0x20u) | ((nb << 3) & 0x40u);
+		}
 		if (state == 0) state = tmp & 7;
 		else if (!(tmp >> (state + 2) & 1)) state = 0;
 		if (state == 0) state = tmp & 7;
