@@ -8,3 +8,4 @@ The directory name carries a hyphen, so import it with ``importlib`` (see ``test
 ``__graft_entry__.py`` does exactly that.
 """
 from .hip_abi import Context, GdietError, KswScore, library_path, load_library, pack, PRESET_SCORES  # noqa: F401
+from .map_api import Mapper, MapOpt, PRESETS as MAP_PRESETS  # noqa: F401,E402

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <thread>
 
 #include "../../include/gdiet_hip.h"
 #include "ksw_common.h"
@@ -31,6 +32,10 @@ struct gdiet_ctx {
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	std::vector<KswTask> h_tasks;
 	std::vector<int32_t> h_ids;
+	// per-read mapping path (map_pipeline.hip.h)
+	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack;
+	int host_threads = 8;
+	double stage_s[6] = {0, 0, 0, 0, 0, 0};
 };
 
 #define GD_HIP(call)                                                                              \
@@ -93,6 +98,7 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 			delete ctx;
 			return GDIET_E_HIP;
 		}
+	ctx->host_threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 	*out = ctx;
 	return GDIET_OK;
 }
@@ -102,7 +108,9 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar};
+	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar,
+	                  &ctx->m_sc, &ctx->m_mv, &ctx->m_u64, &ctx->m_seed, &ctx->m_seedout, &ctx->m_voteout, &ctx->m_hitoff, &ctx->m_hits,
+	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack};
 	for (DevBuf *b : bufs)
 		if (b->p) (void)hipFree(b->p);
 	for (int i = 0; i < 4; ++i)
@@ -364,3 +372,5 @@ extern "C" int gdiet_hip_ksw_extd2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 		}
 	return GDIET_OK;
 }
+
+#include "map_pipeline.hip.h"

@@ -89,9 +89,12 @@ __global__ __launch_bounds__(64) void ksw_extd2_generic_kernel(const KswTask *__
 				const int j = r - t; // query index of cell (r,t); outside [0,qlen) the reference reads zero padding
 				const uint8_t tb = t < tlen ? target[t] : 0;
 				const uint8_t qb = (j >= 0 && j < qlen) ? query[j] : 0;
-				int8_t sc = tb == qb ? sc_mch : sc_mis;
-				if (tb == 4 || qb == 4) sc = sc_N;
-				s[t & mask] = sc;
+				// score table of the parity target's kernel (ksw_extd2_avx512, SR/ksw2_extd2_avx.c:183-209,310-313):
+				// query N is 8, index = low nibble of target ^ query: 0 match, 1-3 mismatch, 4-12 sc_N, 13-15 zero.
+				// Identical to the SSE rule (:165-180) for bytes 0..4; differs for the byte 7 that LR/map.c:1634 produces
+				// for an N of a reverse-complemented read.
+				const int x = (tb ^ (qb == 4 ? 8 : qb)) & 15;
+				s[t & mask] = x == 0 ? sc_mch : x <= 3 ? sc_mis : x <= 12 ? sc_N : (int8_t)0;
 			}
 		}
 		__syncthreads();

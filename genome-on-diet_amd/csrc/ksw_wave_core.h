@@ -135,7 +135,6 @@ struct WaveLane {
 	u32 U[8], V[8], X[8], Y[8], X2[8], Y2[8]; // packed keys, register k = cells (k, k+8) of the lane's block
 	u32 Sb[4];   // S-key bytes, dword g = cells 4g..4g+3 (persistent: stale cells keep their old score)
 	u32 Tb[4];   // target nt4 bytes of the block (0 beyond tlen)
-	u32 TN[4];   // 0x04 where the target byte is N
 	u32 Qc[4];   // query nt4 bytes facing the cells on the current anti-diagonal: cell i <-> query[r - (tb+i)]
 	u32 SEL[4];  // v_perm selectors blending fresh scores into Sb (per byte: 4+i = take fresh, i = keep)
 	int32_t blk; // block index m held by the lane (m mod lanes == lane id)
@@ -162,7 +161,7 @@ GDW_HD void gdw_load_block(WaveLane &L, const WaveK &K, int m, int r, const uint
 			tw |= (t < tlen ? (u32)target[t] : 0u) << (8 * b);
 			qw |= gdw_qbyte(query, qlen, r - t) << (8 * b);
 		}
-		L.Tb[g] = tw, L.TN[g] = tw & 0x04040404u, L.Qc[g] = qw, L.Sb[g] = K.s0, L.SEL[g] = 0x03020100u;
+		L.Tb[g] = tw, L.Qc[g] = qw, L.Sb[g] = K.s0, L.SEL[g] = 0x03020100u;
 	}
 	L.R = 0;
 }
@@ -207,7 +206,10 @@ GDW_HD void gdw_update_scores(WaveLane &L, const WaveK &K)
 {
 #pragma unroll
 	for (int g = 0; g < 4; ++g) {
-		const u32 x = (L.Tb[g] ^ L.Qc[g]) | L.TN[g];     // 0 match, 1-3 mismatch, 4-7 ambiguous (query N = 4)
+		// index of the AVX-512 score table (SR/ksw2_extd2_avx.c:183-209) folded into 3 bits: 0 match, 1-3 mismatch,
+		// 4-7 sc_N.  target ^ query is already right except when both are N (4 ^ 4 = 0): set bit 2 when the target is N
+		// and the query byte is not the reverse-complemented N (7 = 4 ^ 3, which the table scores as a mismatch vs N).
+		const u32 x = (L.Tb[g] ^ L.Qc[g]) | (L.Tb[g] & ~(L.Qc[g] << 1) & 0x04040404u);
 		const u32 fresh = gdw_perm(K.lut_hi, K.lut_lo, x);
 		L.Sb[g] = gdw_perm(fresh, L.Sb[g], L.SEL[g]);
 	}

@@ -1,0 +1,400 @@
+// B1: batch driver of the per-read mapping path.  Included at the end of gdiet_hip.hip (needs gdiet_ctx, GD_HIP, gd_grow).
+//   host threads : encode reads, candidate linking + DP boxes (gd_lr_link_and_boxes), post-processing (gd_lr_finish)
+//   device       : map_seed_kernel -> map_vote_kernel -> map_gather_kernel -> ksw batch (exact-match, DP, backtrack)
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include "map_host.h"
+#include "map_index.h"
+#include "map_kernels.hip.h"
+
+struct gdiet_index {
+	GdIndex h;
+	void *d_tkey = nullptr, *d_tval = nullptr, *d_pos = nullptr, *d_S = nullptr;
+	GdIdxView dview;
+};
+
+struct gdiet_read_batch {
+	int n = 0;
+	std::vector<int64_t> roff;          // n+1
+	std::vector<uint8_t> enc;           // nt4, forward strand, all reads packed (host copy for post-processing)
+	void *d_reads = nullptr, *d_roff = nullptr;
+};
+
+template <class F> static void gd_parallel_for(int n_threads, int n, F f)
+{
+	if (n_threads <= 1 || n < 2) { for (int i = 0; i < n; ++i) f(i); return; }
+	std::atomic<int> next(0);
+	std::vector<std::thread> th;
+	for (int t = 0; t < n_threads; ++t)
+		th.emplace_back([&]() { for (;;) { const int i = next.fetch_add(16); if (i >= n) break; for (int j = i; j < std::min(n, i + 16); ++j) f(j); } });
+	for (auto &t : th) t.join();
+}
+
+static double gd_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int gd_index_upload(gdiet_ctx *ctx, gdiet_index *ix)
+{
+	GdIndex &h = ix->h;
+	auto up = [&](void **d, const void *src, size_t bytes) -> int {
+		if (bytes == 0) bytes = 8;
+		GD_HIP(hipMalloc(d, bytes));
+		if (src) GD_HIP(hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice));
+		return GDIET_OK;
+	};
+	int rc;
+	if ((rc = up(&ix->d_tkey, h.tkey.data(), h.tkey.size() * 8))) return rc;
+	if ((rc = up(&ix->d_tval, h.tval.data(), h.tval.size() * 8))) return rc;
+	if ((rc = up(&ix->d_pos, h.pos.empty() ? nullptr : h.pos.data(), h.pos.size() * 8))) return rc;
+	if ((rc = up(&ix->d_S, h.S.empty() ? nullptr : h.S.data(), h.S.size() * 4 + 8))) return rc;
+	ix->dview.k = h.k, ix->dview.w = h.w, ix->dview.tbits = h.tbits;
+	ix->dview.tkey = (const uint64_t *)ix->d_tkey, ix->dview.tval = (const uint64_t *)ix->d_tval, ix->dview.pos = (const uint64_t *)ix->d_pos;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_index_build(gdiet_ctx *ctx, gdiet_index **out, int n_seq, const char *const *names, const char *const *seqs,
+                                     const uint32_t *lens, int k, int w, const char *pattern, int pattern_len, int n_threads)
+{
+	if (!ctx || !out || n_seq <= 0 || !seqs || !lens) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	GdPattern P;
+	if (!gd_pattern_init(P, pattern, pattern_len)) { ctx->err = "bad pattern"; return GDIET_E_PARAM; }
+	if (w <= 0 || w > GDM_MAX_W || k <= 0 || k > 28) { ctx->err = "k must be in [1,28] and w in [1,64]"; return GDIET_E_PARAM; }
+	gdiet_index *ix = new gdiet_index();
+	std::vector<std::string> nm(n_seq), sq(n_seq);
+	for (int i = 0; i < n_seq; ++i) nm[i] = names && names[i] ? names[i] : "", sq[i].assign(seqs[i], lens[i]);
+	gd_index_build(ix->h, nm, sq, k, w, P, n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency(), true);
+	int rc = gd_index_upload(ctx, ix);
+	if (rc) { delete ix; return rc; }
+	*out = ix;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_index_import(gdiet_ctx *ctx, gdiet_index **out, int k, int w, const char *pattern, int pattern_len, int n_seq,
+                                      const char *const *names, const uint32_t *lens, const uint64_t *offsets, const uint32_t *S,
+                                      uint64_t n_keys, const uint64_t *keys, const uint32_t *cnt, const uint64_t *pos)
+{
+	if (!ctx || !out || n_seq <= 0 || !lens || !offsets || !S || !keys || !cnt || !pos) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	GdPattern P;
+	if (!gd_pattern_init(P, pattern, pattern_len)) { ctx->err = "bad pattern"; return GDIET_E_PARAM; }
+	gdiet_index *ix = new gdiet_index();
+	GdIndex &h = ix->h;
+	h.k = k, h.w = w, h.pat = P;
+	h.seq.resize(n_seq);
+	uint64_t sum = 0;
+	for (int i = 0; i < n_seq; ++i) h.seq[i].name = names && names[i] ? names[i] : "", h.seq[i].len = lens[i], h.seq[i].offset = offsets[i], sum = std::max<uint64_t>(sum, offsets[i] + lens[i]);
+	h.S.assign(S, S + (sum + 7) / 8);
+	h.n_keys = n_keys;
+	h.key_counts.assign(cnt, cnt + n_keys);
+	uint64_t tot = 0;
+	for (uint64_t i = 0; i < n_keys; ++i) tot += cnt[i];
+	h.pos.assign(pos, pos + tot);
+	h.tbits = 4;
+	while ((1ull << h.tbits) < 2 * n_keys + 16) ++h.tbits;
+	h.tkey.assign(1ull << h.tbits, UINT64_MAX), h.tval.assign(1ull << h.tbits, 0);
+	const uint32_t mask = (uint32_t)((1ull << h.tbits) - 1);
+	uint64_t st = 0;
+	for (uint64_t i = 0; i < n_keys; ++i) {
+		uint32_t s = gd_idx_slot(keys[i], h.tbits);
+		while (h.tkey[s] != UINT64_MAX) s = (s + 1) & mask;
+		h.tkey[s] = keys[i], h.tval[s] = st << 32 | cnt[i];
+		st += cnt[i];
+	}
+	int rc = gd_index_upload(ctx, ix);
+	if (rc) { delete ix; return rc; }
+	*out = ix;
+	return GDIET_OK;
+}
+
+extern "C" void gdiet_hip_index_destroy(gdiet_ctx *ctx, gdiet_index *ix)
+{
+	if (!ix) return;
+	if (ctx) (void)hipSetDevice(ctx->device);
+	void *p[] = {ix->d_tkey, ix->d_tval, ix->d_pos, ix->d_S};
+	for (void *q : p) if (q) (void)hipFree(q);
+	delete ix;
+}
+
+extern "C" int32_t gdiet_hip_index_cal_max_occ(const gdiet_index *ix, float frac) { return ix ? gd_index_cal_max_occ(ix->h, frac) : 0; }
+extern "C" uint64_t gdiet_hip_index_n_keys(const gdiet_index *ix) { return ix ? ix->h.n_keys : 0; }
+
+extern "C" int gdiet_hip_set_host_threads(gdiet_ctx *ctx, int n)
+{
+	if (!ctx || n < 1) return GDIET_E_PARAM;
+	ctx->host_threads = n;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_map_stage_seconds(const gdiet_ctx *ctx, double out[6])
+{
+	if (!ctx || !out) return GDIET_E_PARAM;
+	for (int i = 0; i < 6; ++i) out[i] = ctx->stage_s[i];
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **out, int n, const char *const *seqs, const int32_t *lens)
+{
+	if (!ctx || !out || n < 0 || (n && (!seqs || !lens))) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	gdiet_read_batch *b = new gdiet_read_batch();
+	b->n = n;
+	b->roff.assign(n + 1, 0);
+	for (int i = 0; i < n; ++i) b->roff[i + 1] = b->roff[i] + (lens[i] > 0 ? lens[i] : 0);
+	b->enc.resize((size_t)b->roff[n] + 8);
+	gd_parallel_for(ctx->host_threads, n, [&](int i) {
+		uint8_t *d = b->enc.data() + b->roff[i];
+		for (int j = 0; j < lens[i]; ++j) d[j] = gd_nt4((unsigned char)seqs[i][j]);
+	});
+	hipError_t e = hipMalloc(&b->d_reads, b->enc.size());
+	if (e == hipSuccess) e = hipMalloc(&b->d_roff, sizeof(int64_t) * (n + 1));
+	if (e == hipSuccess) e = hipMemcpy(b->d_reads, b->enc.data(), b->enc.size(), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(b->d_roff, b->roff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice);
+	if (e != hipSuccess) { ctx->err = std::string("batch upload: ") + hipGetErrorString(e); delete b; return GDIET_E_HIP; }
+	*out = b;
+	return GDIET_OK;
+}
+
+extern "C" void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *b)
+{
+	if (!b) return;
+	if (ctx) (void)hipSetDevice(ctx->device);
+	if (b->d_reads) (void)hipFree(b->d_reads);
+	if (b->d_roff) (void)hipFree(b->d_roff);
+	delete b;
+}
+
+static void gd_regs_out(const std::vector<GdReg> &v, int32_t *n_regs, gdiet_reg_t **regs)
+{
+	*n_regs = (int32_t)v.size();
+	*regs = nullptr;
+	if (v.empty()) return;
+	gdiet_reg_t *r = (gdiet_reg_t *)calloc(v.size(), sizeof(gdiet_reg_t));
+	for (size_t i = 0; i < v.size(); ++i) {
+		const GdReg &g = v[i];
+		r[i].id = g.id, r[i].cnt = g.cnt, r[i].rid = g.rid, r[i].score = g.score, r[i].qs = g.qs, r[i].qe = g.qe, r[i].rs = g.rs, r[i].re = g.re;
+		r[i].parent = g.parent, r[i].subsc = g.subsc, r[i].mlen = g.mlen, r[i].blen = g.blen, r[i].mapq = g.mapq, r[i].rev = g.rev, r[i].sam_pri = g.sam_pri;
+		r[i].dp_score = g.dp_score, r[i].dp_max = g.dp_max, r[i].n_ambi = g.n_ambi, r[i].n_cigar = (uint32_t)g.cigar.size();
+		r[i].cigar = (uint32_t *)malloc(g.cigar.size() * 4 + 4);
+		if (!g.cigar.empty()) memcpy(r[i].cigar, g.cigar.data(), g.cigar.size() * 4);
+	}
+	*regs = r;
+}
+
+extern "C" void gdiet_hip_free_regs(int n, int32_t *n_regs, gdiet_reg_t **regs)
+{
+	if (!n_regs || !regs) return;
+	for (int i = 0; i < n; ++i) {
+		for (int j = 0; j < n_regs[i]; ++j) free(regs[i][j].cigar);
+		free(regs[i]);
+		regs[i] = nullptr, n_regs[i] = 0;
+	}
+}
+
+static void gd_opt_from_c(const gdiet_mapopt_t *o, const gdiet_index *ix, GdMapOpt &O)
+{
+	O.flag = o->flag, O.k = ix->h.k, O.w = ix->h.w, O.a = o->a, O.b = o->b, O.q = o->q, O.e = o->e, O.q2 = o->q2, O.e2 = o->e2;
+	O.bw = o->bw, O.min_dp_max = o->min_dp_max, O.best_n = o->best_n, O.q_occ_frac = o->q_occ_frac, O.mid_occ = o->mid_occ;
+	O.max_max_occ = o->max_max_occ, O.occ_dist = o->occ_dist, O.max_frag_len = o->max_frag_len, O.vt_dis = o->vt_dis, O.vt_nb_loc = o->vt_nb_loc;
+	O.vt_cov = o->vt_cov, O.vt_f = o->vt_f, O.vt_df1 = o->vt_df1, O.vt_df2 = o->vt_df2, O.max_max_gap = o->max_max_gap, O.max_min_gap = o->max_min_gap;
+	O.max_seeds = o->max_seeds, O.pat = ix->h.pat;
+}
+
+extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, const gdiet_mapopt_t *copt, gdiet_read_batch *B,
+                                      int32_t *n_regs, gdiet_reg_t **regs)
+{
+	if (!ctx || !ix || !copt || !B || !n_regs || !regs) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	const int n = B->n;
+	for (int i = 0; i < 6; ++i) ctx->stage_s[i] = 0;
+	if (n == 0) return GDIET_OK;
+	GdMapOpt O;
+	gd_opt_from_c(copt, ix, O);
+	if (O.flag & GD_F_SR) { ctx->err = "the ShortReads variant of mm_map_frag is not implemented yet (LongReads only)"; return GDIET_E_PARAM; }
+	if (O.vt_nb_loc + 2 > GDM_MAX_VT) { ctx->err = "vt_nb_loc too large"; return GDIET_E_PARAM; }
+	if (O.mid_occ <= 0) { ctx->err = "mid_occ must be set (mm_mapopt_update)"; return GDIET_E_PARAM; }
+	hipStream_t s = ctx->stream;
+	int rc;
+	double t0 = gd_now();
+	// ---- scratch layout -------------------------------------------------------------------------------------------
+	std::vector<MapReadScratch> sc(n);
+	uint64_t tot = 0;
+	for (int i = 0; i < n; ++i) {
+		const uint32_t len = (uint32_t)(B->roff[i + 1] - B->roff[i]);
+		sc[i].mv_cap = len / 3 + 512, sc[i].mv_off = tot, sc[i].u64_off = 2 * tot, sc[i].seed_off = tot, sc[i].pad = 0;
+		tot += sc[i].mv_cap;
+	}
+	if ((rc = gd_grow(ctx, ctx->m_sc, sizeof(MapReadScratch) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->m_mv, sizeof(GdMini) * tot))) return rc;
+	if ((rc = gd_grow(ctx, ctx->m_u64, sizeof(uint64_t) * 2 * tot))) return rc;
+	if ((rc = gd_grow(ctx, ctx->m_seed, sizeof(GdSeed) * tot))) return rc;
+	if ((rc = gd_grow(ctx, ctx->m_seedout, sizeof(MapSeedOut) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->m_voteout, sizeof(MapVoteOut) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->m_hitoff, sizeof(int64_t) * (n + 1)))) return rc;
+	GD_HIP(hipMemcpyAsync(ctx->m_sc.p, sc.data(), sizeof(MapReadScratch) * n, hipMemcpyHostToDevice, s));
+	MapDevOpt D;
+	D.k = O.k, D.w = O.w, D.max_seeds = O.max_seeds, D.q_occ_frac = O.q_occ_frac, D.mid_occ = O.mid_occ, D.max_max_occ = O.max_max_occ, D.occ_dist = O.occ_dist;
+	D.max_nb_seeds = (O.flag & GD_F_FRAG_MODE) ? (O.max_frag_len == 0 ? 800u : (uint32_t)O.max_frag_len) : UINT32_MAX;
+	D.flag = O.flag, D.pat = O.pat;
+	D.vote.vt_dis = O.vt_dis, D.vote.vt_nb_loc = O.vt_nb_loc, D.vote.bw = O.bw, D.vote.vt_cov = O.vt_cov, D.vote.vt_f = O.vt_f;
+	D.vote.vt_df1 = O.vt_df1, D.vote.vt_df2 = O.vt_df2, D.vote.k = O.k;
+	const uint8_t *d_reads = (const uint8_t *)B->d_reads;
+	const int64_t *d_roff = (const int64_t *)B->d_roff;
+	ctx->stage_s[5] += gd_now() - t0, t0 = gd_now();
+	// ---- S1-S5 ----------------------------------------------------------------------------------------------------
+	hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+	                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
+	std::vector<MapSeedOut> so(n);
+	GD_HIP(hipMemcpyAsync(so.data(), ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipStreamSynchronize(s));
+	ctx->stage_s[0] += gd_now() - t0, t0 = gd_now();
+	std::vector<int64_t> hoff(n + 1, 0);
+	for (int i = 0; i < n; ++i) {
+		if (so[i].n_seeds < 0) { ctx->err = "minimizer scratch overflow for read " + std::to_string(i); return GDIET_E_NOMEM; }
+		hoff[i + 1] = hoff[i] + (so[i].n_seeds > 0 ? so[i].n_a : 0);
+	}
+	if ((rc = gd_grow(ctx, ctx->m_hits, sizeof(GdLoc) * 3 * (size_t)(hoff[n] + 1)))) return rc;
+	GD_HIP(hipMemcpyAsync(ctx->m_hitoff.p, hoff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s));
+	// ---- S6, S7, V1, V3, G1a -----------------------------------------------------------------------------------------
+	hipLaunchKernelGGL(map_vote_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+	                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
+	                   (MapVoteOut *)ctx->m_voteout.p);
+	std::vector<MapVoteOut> vo(n);
+	GD_HIP(hipMemcpyAsync(vo.data(), ctx->m_voteout.p, sizeof(MapVoteOut) * n, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipStreamSynchronize(s));
+	ctx->stage_s[1] += gd_now() - t0, t0 = gd_now();
+	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
+	const GdRefView R = ix->h.ref();
+	std::vector<std::vector<GdCand>> cand(n);
+	gd_parallel_for(ctx->host_threads, n, [&](int i) {
+		const unsigned nc = vo[i].n_cand;
+		if (!nc) return;
+		cand[i].resize(nc);
+		for (unsigned j = 0; j < nc; ++j) cand[i][j].v = vo[i].cand[j];
+		gd_lr_link_and_boxes(cand[i], O, R, (uint32_t)(B->roff[i + 1] - B->roff[i]));
+	});
+	std::vector<int> box_first(n + 1, 0);
+	for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + (int)cand[i].size();
+	const int nb = box_first[n];
+	std::vector<MapBox> boxes(nb);
+	std::vector<int64_t> qoff(nb + 1, 0), toff(nb + 1, 0), coff(nb + 1, 0);
+	std::vector<int32_t> bw(nb), ex(nb);
+	bool bad_box = false;
+	for (int i = 0; i < n; ++i)
+		for (size_t j = 0; j < cand[i].size(); ++j) {
+			const GdCand &c = cand[i][j];
+			const int b = box_first[i] + (int)j;
+			const uint32_t rl = (uint32_t)(B->roff[i + 1] - B->roff[i]);
+			MapBox &M = boxes[b];
+			M.read_off = B->roff[i], M.read_len = rl, M.qseq_off = c.qseq_off, M.qlen = c.qlen, M.tlen = c.tlen, M.rev = c.v.str;
+			// a window hanging off a contig (or a wrapped coordinate) reads stale memory in the reference; here the part that
+			// does not exist is zero-filled and absurd sizes are refused
+			uint32_t avail = 0;
+			uint64_t src = 0;
+			if (c.target_id < R.n_seq && c.target_start < R.seq[c.target_id].len) {
+				avail = std::min<uint32_t>(c.tlen, R.seq[c.target_id].len - c.target_start);
+				src = R.seq[c.target_id].offset + c.target_start;
+			}
+			M.t_avail = avail, M.t_src = src;
+			if (c.qlen == 0 || c.tlen == 0 || c.qlen > rl || c.qseq_off + c.qlen > rl || c.tlen > 8u * rl + 100000u) bad_box = true;
+			M.q_dst = qoff[b], M.t_dst = toff[b];
+			qoff[b + 1] = qoff[b] + c.qlen, toff[b + 1] = toff[b] + c.tlen;
+			coff[b + 1] = coff[b] + c.qlen + c.tlen;
+			bw[b] = (int32_t)O.bw, ex[b] = c.exact_score;
+		}
+	if (bad_box) { ctx->err = "degenerate DP box (candidate window outside the read/contig); the reference's behaviour is undefined there"; return GDIET_E_PARAM; }
+	ctx->stage_s[2] += gd_now() - t0, t0 = gd_now();
+	std::vector<int32_t> h_score(nb), h_ncig(nb);
+	std::vector<uint32_t> h_cig;
+	std::vector<int64_t> poff(1, 0);
+	if (nb > 0) {
+		if ((rc = gd_grow(ctx, ctx->m_boxes, sizeof(MapBox) * nb))) return rc;
+		if ((rc = gd_grow(ctx, ctx->m_q, (size_t)qoff[nb] + 64))) return rc;
+		if ((rc = gd_grow(ctx, ctx->m_t, (size_t)toff[nb] + 64))) return rc;
+		if ((rc = gd_grow(ctx, ctx->m_aux, sizeof(int64_t) * (nb + 1) + sizeof(int32_t) * 3 * nb + 64))) return rc;
+		if ((rc = gd_grow(ctx, ctx->m_cig, sizeof(uint32_t) * ((size_t)coff[nb] + 1)))) return rc;
+		int64_t *d_coff = (int64_t *)ctx->m_aux.p;
+		int32_t *d_ex = (int32_t *)(d_coff + nb + 1), *d_score = d_ex + nb, *d_ncig = d_score + nb;
+		GD_HIP(hipMemcpyAsync(ctx->m_boxes.p, boxes.data(), sizeof(MapBox) * nb, hipMemcpyHostToDevice, s));
+		GD_HIP(hipMemcpyAsync(d_coff, coff.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, s));
+		GD_HIP(hipMemcpyAsync(d_ex, ex.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(64), 0, s, nb, (const MapBox *)ctx->m_boxes.p, d_reads, (const uint32_t *)ix->d_S,
+		                   (uint8_t *)ctx->m_q.p, (uint8_t *)ctx->m_t.p);
+		gdiet_ksw_score_t ks;
+		ks.match = (int8_t)O.a, ks.mismatch = (int8_t)(O.b < 0 ? O.b : -O.b), ks.sc_ambi = 0, ks.q = (int8_t)O.q, ks.e = (int8_t)O.e, ks.q2 = (int8_t)O.q2, ks.e2 = (int8_t)O.e2;
+		ks.reserved = 0, ks.flag = GDIET_EZ_APPROX_MAX;
+		rc = gdiet_hip_ksw_extd2_batch_dev(ctx, nb, (const uint8_t *)ctx->m_q.p, nullptr, (const uint8_t *)ctx->m_t.p, nullptr, nullptr, d_ex, &ks, d_score, d_ncig,
+		                                   (uint32_t *)ctx->m_cig.p, d_coff, qoff.data(), toff.data(), bw.data(), s);
+		if (rc) return rc;
+		GD_HIP(hipMemcpyAsync(h_score.data(), d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s));
+		GD_HIP(hipMemcpyAsync(h_ncig.data(), d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s));
+		GD_HIP(hipStreamSynchronize(s));
+		// CIGARs are short compared with their capacity (qlen+tlen): pack them on the device, then one copy
+		for (int b = 0; b < nb; ++b) if (h_ncig[b] > coff[b + 1] - coff[b]) { ctx->err = "CIGAR capacity exceeded"; return GDIET_E_CIGAR_CAP; }
+		poff.assign(nb + 1, 0);
+		for (int b = 0; b < nb; ++b) poff[b + 1] = poff[b] + std::max(h_ncig[b], 0);
+		h_cig.resize((size_t)poff[nb] + 1);
+		if (poff[nb] > 0) {
+			if ((rc = gd_grow(ctx, ctx->m_pack, sizeof(uint32_t) * (size_t)poff[nb] + sizeof(int64_t) * (nb + 1) + 64))) return rc;
+			int64_t *d_poff = (int64_t *)ctx->m_pack.p;
+			uint32_t *d_packed = (uint32_t *)(d_poff + nb + 1);
+			GD_HIP(hipMemcpyAsync(d_poff, poff.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, s));
+			hipLaunchKernelGGL(map_pack_cigar_kernel, dim3(nb), dim3(64), 0, s, nb, (const uint32_t *)ctx->m_cig.p, (const int64_t *)d_coff, (const int64_t *)d_poff, d_packed);
+			GD_HIP(hipMemcpyAsync(h_cig.data(), d_packed, sizeof(uint32_t) * (size_t)poff[nb], hipMemcpyDeviceToHost, s));
+			GD_HIP(hipStreamSynchronize(s));
+		}
+	}
+	ctx->stage_s[3] += gd_now() - t0, t0 = gd_now();
+	// ---- P1-P3 (host threads) ---------------------------------------------------------------------------------------------
+	gd_parallel_for(ctx->host_threads, n, [&](int i) {
+		n_regs[i] = 0, regs[i] = nullptr;
+		const size_t nc = cand[i].size();
+		if (!nc) return;
+		const uint32_t rl = (uint32_t)(B->roff[i + 1] - B->roff[i]);
+		const uint8_t *enc = B->enc.data() + B->roff[i];
+		std::vector<uint8_t> rev;
+		bool need_rev = false;
+		for (auto &c : cand[i]) need_rev |= c.v.str != 0;
+		if (need_rev) { rev.resize(rl); for (uint32_t j = 0; j < rl; ++j) rev[rl - 1 - j] = enc[j] ^ 3; }
+		std::vector<GdDpResult> dp(nc);
+		for (size_t j = 0; j < nc; ++j) {
+			const int b = box_first[i] + (int)j;
+			dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig.data() + poff[b];
+		}
+		std::vector<GdReg> out;
+		gd_lr_finish(cand[i], dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
+		gd_regs_out(out, &n_regs[i], &regs[i]);
+	});
+	ctx->stage_s[4] += gd_now() - t0;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_map_batch(gdiet_ctx *ctx, const gdiet_index *ix, const gdiet_mapopt_t *opt, int n, const char *const *seqs,
+                                   const int32_t *lens, int32_t *n_regs, gdiet_reg_t **regs)
+{
+	gdiet_read_batch *b = nullptr;
+	int rc = gdiet_hip_batch_upload(ctx, &b, n, seqs, lens);
+	if (rc) return rc;
+	rc = gdiet_hip_map_uploaded(ctx, ix, opt, b, n_regs, regs);
+	gdiet_hip_batch_destroy(ctx, b);
+	return rc;
+}
+
+extern "C" size_t gdiet_hip_sam_record(const gdiet_index *ix, const char *qname, const char *seq, const char *qual, int32_t l_seq,
+                                       const gdiet_reg_t *regs, int32_t n_regs, int32_t reg_idx, int64_t opt_flag, char *buf, size_t cap)
+{
+	if (!ix) return 0;
+	std::vector<GdReg> v(n_regs > 0 ? n_regs : 0);
+	for (int i = 0; i < n_regs; ++i) {
+		const gdiet_reg_t &r = regs[i];
+		GdReg &g = v[i];
+		g.id = r.id, g.cnt = r.cnt, g.rid = r.rid, g.score = r.score, g.qs = r.qs, g.qe = r.qe, g.rs = r.rs, g.re = r.re, g.parent = r.parent, g.subsc = r.subsc;
+		g.mlen = r.mlen, g.blen = r.blen, g.mapq = r.mapq, g.rev = r.rev, g.sam_pri = r.sam_pri, g.dp_score = r.dp_score, g.dp_max = r.dp_max, g.n_ambi = r.n_ambi;
+		g.has_p = true, g.cigar.assign(r.cigar, r.cigar + r.n_cigar);
+	}
+	std::string s;
+	gd_write_sam(s, ix->h.ref(), qname, seq, qual, l_seq, v, reg_idx, opt_flag);
+	if (buf && cap) { const size_t m = std::min(cap - 1, s.size()); memcpy(buf, s.data(), m); buf[m] = 0; }
+	return s.size();
+}

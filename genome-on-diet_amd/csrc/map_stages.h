@@ -1,0 +1,561 @@
+// S1-S7 / V1,V3 of SURVEY.md 8a: the per-read seeding and voting stages of mm_map_frag (LongReads variant),
+// written once as host/device functions.  On the GPU they run one read per thread (map_kernels.hip.h); the same
+// code is compiled for the host by the CPU tests (tests/emul/stages_host.cpp) to be checked against the reference
+// without a GPU.  Input sequences are nt4 bytes (0-3 = ACGT, 4 = N): seq_nt4_table maps those bytes to themselves
+// (LR/sketch.c:11-18, first five entries), so sketching the encoded read equals sketching the ASCII read.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GDM_HD __host__ __device__ inline
+#define GDM_HDM __host__ __device__ inline // member functions
+#else
+#define GDM_HD static inline
+#define GDM_HDM inline
+#endif
+
+#define GDM_MAX_W 64      // window sizes above this are rejected by the planner (the reference allows < 256)
+#define GDM_MAX_ONES 40   // LR/sketch.c:1927
+
+struct GdMini { uint64_t x, y; }; // mm128_t: x = hash<<8 | span, y = rid<<32 | lastPos<<1 | strand (LR/minimap.h:69-72)
+
+struct GdPattern { // -Z / -W
+	int W, ones;
+	int ones_loc[GDM_MAX_ONES];
+	char Z[64];
+};
+
+static inline bool gd_pattern_init(GdPattern &P, const char *Z, int W)
+{
+	if (W <= 0 || W > 63) return false;
+	P.W = W, P.ones = 0;
+	for (int g = 0; g < W; ++g) {
+		P.Z[g] = Z[g];
+		if (Z[g] == '1') { if (P.ones >= GDM_MAX_ONES) return false; P.ones_loc[P.ones++] = g; }
+	}
+	P.Z[W] = 0;
+	return P.ones > 0;
+}
+
+// Thomas Wang's invertible integer hash, LR/sketch.c:25-34
+GDM_HD uint64_t gd_hash64(uint64_t key, uint64_t mask)
+{
+	key = (~key + (key << 21)) & mask;
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8)) & mask;
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4)) & mask;
+	key = key ^ key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+// number of pattern-1 positions in [shift, len)  (LR/sketch.c:1942-1948, :2187-2193)
+GDM_HD unsigned gd_diet_len(const GdPattern &P, unsigned len, unsigned shift)
+{
+	if (shift > len) return 0; // the reference underflows here (reads shorter than the pattern phase); never reached by real reads
+	unsigned d = ((len - shift) / P.W) * P.ones, off = (len - shift) % P.W;
+	for (unsigned i = 0; i < off; ++i)
+		if (P.Z[i] == '1') ++d;
+	return d;
+}
+
+// The winnowing automaton shared by mm_sketch (:1640-1765), mm_sketch2_sub (:1780-1905) and mm_sketch3 (:1968-2138).
+// `emit(m)` is called for every minimizer the reference pushes, in the same order; it returns true to stop
+// (the two capped variants return from inside the loop).  final_ge: the final flush uses l >= w+k-1 (sketch2/3 and the
+// AVX-512 mm_sketch, :607) instead of l > w+k-1 (scalar mm_sketch, :1760).
+template <class Emit>
+GDM_HD void gd_sketch_core(const uint8_t *str, unsigned diet_len, int w, int k, uint32_t rid, unsigned shift,
+                           const GdPattern &P, bool final_ge, Emit &emit)
+{
+	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+	uint64_t kmer[2] = {0, 0};
+	GdMini buf[GDM_MAX_W], mn = {UINT64_MAX, UINT64_MAX};
+	int l = 0, buf_pos = 0, min_pos = 0;
+	for (int j = 0; j < w; ++j) buf[j].x = buf[j].y = UINT64_MAX;
+	for (unsigned i = 0; i < diet_len; ++i) {
+		const unsigned real = (i / P.ones) * P.W + P.ones_loc[i % P.ones] + shift; // get_real_location, :20-23
+		const int c = str[real] < 4 ? str[real] : 4;
+		GdMini info = {UINT64_MAX, UINT64_MAX};
+		if (c < 4) {
+			const int span = l + 1 < k ? l + 1 : k;
+			kmer[0] = (kmer[0] << 2 | (uint64_t)c) & mask;
+			kmer[1] = (kmer[1] >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+			++l;
+			if (kmer[0] != kmer[1]) { // palindromic k-mers are skipped (strand unknown)
+				const int z = kmer[0] < kmer[1] ? 0 : 1;
+				if (l >= k) {
+					info.x = gd_hash64(kmer[z], mask) << 8 | (uint64_t)span;
+					info.y = (uint64_t)rid << 32 | (uint64_t)(uint32_t)real << 1 | (uint64_t)z;
+				}
+			}
+		} else {
+			if (l >= w + k - 1 && mn.x != UINT64_MAX)
+				if (emit(mn)) return;
+			l = 0;
+		}
+		buf[buf_pos] = info;
+		if (info.x <= mn.x) { // a new minimum (ties: the rightmost wins); write the old one
+			if (l >= w + k && mn.x != UINT64_MAX)
+				if (emit(mn)) return;
+			mn = info, min_pos = buf_pos;
+		} else if (buf_pos == min_pos) { // the old minimum left the window
+			if (l >= w + k - 1 && mn.x != UINT64_MAX)
+				if (emit(mn)) return;
+			mn.x = UINT64_MAX;
+			for (int j = buf_pos + 1; j < w; ++j)
+				if (mn.x >= buf[j].x) mn = buf[j], min_pos = j;
+			for (int j = 0; j <= buf_pos; ++j)
+				if (mn.x >= buf[j].x) mn = buf[j], min_pos = j;
+			if (l >= w + k - 1 && mn.x != UINT64_MAX) { // identical k-mers in the window
+				for (int j = buf_pos + 1; j < w; ++j)
+					if (mn.x == buf[j].x && mn.y != buf[j].y)
+						if (emit(buf[j])) return;
+				for (int j = 0; j <= buf_pos; ++j)
+					if (mn.x == buf[j].x && mn.y != buf[j].y)
+						if (emit(buf[j])) return;
+			}
+		}
+		if (l == w + k - 1 && mn.x != UINT64_MAX) { // first full window: identical k-mers were not written yet
+			for (int j = buf_pos + 1; j < w; ++j)
+				if (mn.x == buf[j].x && buf[j].y != mn.y)
+					if (emit(buf[j])) return;
+			for (int j = 0; j < buf_pos; ++j)
+				if (mn.x == buf[j].x && buf[j].y != mn.y)
+					if (emit(buf[j])) return;
+		}
+		if (++buf_pos == w) buf_pos = 0;
+	}
+	if ((final_ge ? l >= w + k - 1 : l > w + k - 1) && mn.x != UINT64_MAX) emit(mn);
+}
+
+// ---- flat index view (device mirror of mm_idx_t's buckets; built by map_index.h) -------------------------------
+// open-addressing table keyed by the minimizer hash value (x >> 8); every key owns a run of the position array
+// sorted by y, exactly the order mm_idx_get returns (LR/index.c:84-100,241-264; singletons included).
+struct GdIdxView {
+	int32_t k, w;
+	uint32_t tbits;        // table has 1 << tbits slots
+	const uint64_t *tkey;  // UINT64_MAX = empty
+	const uint64_t *tval;  // start << 32 | n   (start < 2^32: at most 4G positions)
+	const uint64_t *pos;   // y values
+};
+
+GDM_HD uint32_t gd_idx_slot(uint64_t minier, uint32_t tbits) { return (uint32_t)((minier * 0x9E3779B97F4A7C15ULL) >> (64 - tbits)); }
+
+// mm_idx_get: number of occurrences (0 if absent) and the start of the run in pos[]
+GDM_HD uint32_t gd_idx_get(const GdIdxView &I, uint64_t minier, uint64_t *start)
+{
+	const uint32_t m = (1u << I.tbits) - 1;
+	uint32_t s = gd_idx_slot(minier, I.tbits);
+	for (;;) {
+		const uint64_t kk = I.tkey[s];
+		if (kk == minier) {
+			const uint64_t v = I.tval[s];
+			*start = v >> 32;
+			return (uint32_t)v;
+		}
+		if (kk == UINT64_MAX) return 0;
+		s = (s + 1) & m;
+	}
+}
+
+// ---- S1: mm_sketch2 (LR/sketch.c:2143-2225) -------------------------------------------------------------------
+struct GdEmitCount { // mm_sketch2_sub: append, count, stop at the cap (:1817-1820 ...)
+	GdMini *out;
+	unsigned n, cap_n, max_out;
+	bool overflow;
+	GDM_HDM bool operator()(const GdMini &m)
+	{
+		if (n < max_out) out[n] = m; else overflow = true;
+		++n;
+		return n == cap_n;
+	}
+};
+
+// writes all phases' seeds to out[] back to back, counts per phase to shift_n[W]; returns total (or ~0u on overflow)
+GDM_HD unsigned gd_sketch2(const uint8_t *str, int len, int w, int k, const GdPattern &P, float max_seeds, GdMini *out,
+                           unsigned max_out, uint32_t *shift_n)
+{
+	unsigned len_crop, total = 0;
+	uint32_t cap;
+	if (max_seeds < 1) len_crop = (unsigned)((float)max_seeds * len), cap = UINT32_MAX;
+	else len_crop = len, cap = (uint32_t)max_seeds;
+	for (int shift = 0; shift < P.W; ++shift) {
+		const unsigned dl = gd_diet_len(P, len_crop, shift);
+		GdEmitCount e = {out + total, 0, cap, max_out - total, false};
+		gd_sketch_core(str, dl, w, k, 0, shift, P, true, e);
+		if (e.overflow) return ~0u;
+		shift_n[shift] = e.n;
+		total += e.n;
+		if (cap == UINT32_MAX) len_crop = len, cap = e.n;
+	}
+	return total;
+}
+
+// ---- S3: mm_get_shift (LR/seed.c:166-194) -----------------------------------------------------------------------
+GDM_HD unsigned gd_get_shift(const GdIdxView &I, const GdMini *mv, const uint32_t *shift_n, int W)
+{
+	unsigned shift = 0, best = 0;
+	const GdMini *p = mv;
+	for (int i = 0; i < W; ++i) {
+		unsigned cur = 0;
+		for (uint32_t k = 0; k < shift_n[i]; ++k) {
+			uint64_t st;
+			cur += gd_idx_get(I, p[k].x >> 8, &st);
+		}
+		if (cur > best) shift = i, best = cur;
+		p += shift_n[i];
+	}
+	return shift;
+}
+
+// ---- S2: mm_sketch3 (LR/sketch.c:1908-2139) ---------------------------------------------------------------------
+struct GdEmitCap { // push; when p->n == MAX_NB_SEEDS return that seed's real location (:2010-2012 ...)
+	GdMini *out;
+	unsigned n, cap_n, max_out;
+	uint32_t ret;
+	bool overflow;
+	GDM_HDM bool operator()(const GdMini &m)
+	{
+		if (n < max_out) out[n] = m; else overflow = true;
+		++n;
+		if (n == cap_n) { ret = (uint32_t)(m.y >> 1); return true; }
+		return false;
+	}
+};
+
+// returns tmp_extracted_len; *n_out = number of minimizers (or ~0u on overflow of out[])
+GDM_HD unsigned gd_sketch3(const uint8_t *str, unsigned len, int w, int k, const GdPattern &P, int shift,
+                           uint32_t max_nb_seeds, GdMini *out, unsigned max_out, unsigned *n_out)
+{
+	if (shift < 0) shift = 0;
+	const unsigned dl = gd_diet_len(P, len, (unsigned)shift);
+	GdEmitCap e = {out, 0, max_nb_seeds, max_out, len, false};
+	gd_sketch_core(str, dl, w, k, 0, (unsigned)shift, P, true, e);
+	*n_out = e.overflow ? ~0u : e.n;
+	return e.ret;
+}
+
+// ---- small in-place sorts used per read (one thread per read; n is a few hundred to a few thousand) ---------------
+// bottom-up merge sort of 64-bit keys with a scratch buffer; returns the buffer that holds the result
+GDM_HD uint64_t *gd_msort_u64(uint64_t *a, uint64_t *tmp, unsigned n)
+{
+	for (unsigned wd = 1; wd < n; wd <<= 1) {
+		for (unsigned lo = 0; lo < n; lo += 2 * wd) {
+			unsigned mid = lo + wd < n ? lo + wd : n, hi = lo + 2 * wd < n ? lo + 2 * wd : n;
+			unsigned i = lo, j = mid, o = lo;
+			while (i < mid && j < hi) tmp[o++] = a[j] < a[i] ? a[j++] : a[i++];
+			while (i < mid) tmp[o++] = a[i++];
+			while (j < hi) tmp[o++] = a[j++];
+		}
+		uint64_t *t = a; a = tmp; tmp = t;
+	}
+	return a;
+}
+
+// ---- S4: mm_seed_mz_flt (LR/seed.c:5-29) ---------------------------------------------------------------------------
+// drop query minimizers whose hash occurs more than q_occ_max times in the read and more than n*q_occ_frac.
+// scratch: 2*n uint64.  returns the new count.
+GDM_HD unsigned gd_mz_flt(GdMini *mv, unsigned n, int32_t q_occ_max, float q_occ_frac, uint64_t *scratch)
+{
+	if ((int64_t)n <= (int64_t)q_occ_max || q_occ_frac <= 0.0f || q_occ_max <= 0) return n;
+	// all spans are equal (k), so sorting x sorts the hash; find over-frequent x values
+	uint64_t *a = scratch, *t = scratch + n;
+	for (unsigned i = 0; i < n; ++i) a[i] = mv[i].x;
+	uint64_t *s = gd_msort_u64(a, t, n);
+	uint64_t *bad = (s == a) ? t : a; // list of over-frequent x values (sorted)
+	unsigned nbad = 0;
+	for (unsigned st = 0, i = 1; i <= n; ++i)
+		if (i == n || s[i] != s[st]) {
+			const int32_t cnt = (int32_t)(i - st);
+			if (cnt > q_occ_max && (float)cnt > (float)n * q_occ_frac) bad[nbad++] = s[st]; // nbad <= st: no overlap with unread s[]
+			st = i;
+		}
+	if (nbad == 0) return n;
+	unsigned j = 0;
+	for (unsigned i = 0; i < n; ++i) {
+		unsigned lo = 0, hi = nbad; // binary search
+		const uint64_t x = mv[i].x;
+		while (lo < hi) { unsigned md = (lo + hi) >> 1; if (bad[md] < x) lo = md + 1; else hi = md; }
+		if (!(lo < nbad && bad[lo] == x) && mv[i].x != 0) mv[j++] = mv[i];
+	}
+	return j;
+}
+
+// ---- S5: mm_collect_matches2 = mm_seed_collect_all + mm_seed_select + filter (LR/seed.c:36-164) ---------------------
+struct GdSeed { // mm_seed_t (LR/mmpriv.h:43-49) reduced to what the live path reads
+	uint32_t n;      // occurrences in the index
+	uint32_t q_pos;  // lastPos<<1 | strand of the query minimizer
+	uint32_t start;  // start of the run in the index position array
+	uint32_t flt;
+};
+
+#define GDM_MAX_MAX_HIGH_OCC 128
+
+GDM_HD void gd_seed_select(int32_t n, GdSeed *a, int len, int max_occ, int max_max_occ, int dist)
+{
+	uint64_t b[GDM_MAX_MAX_HIGH_OCC];
+	int32_t i, last0, m;
+	if (n == 0 || n == 1) return;
+	for (i = m = 0; i < n; ++i)
+		if ((int32_t)a[i].n > max_occ) ++m;
+	if (m == 0) return;
+	for (i = 0, last0 = -1; i <= n; ++i) {
+		if (i == n || (int32_t)a[i].n <= max_occ) {
+			if (i - last0 > 1) {
+				const int32_t ps = last0 < 0 ? 0 : (int32_t)(a[last0].q_pos >> 1);
+				const int32_t pe = i == n ? len : (int32_t)(a[i].q_pos >> 1);
+				int32_t j, k, st = last0 + 1, en = i;
+				int32_t max_high_occ = (int32_t)((double)(pe - ps) / dist + .499);
+				if (max_high_occ > 0) {
+					if (max_high_occ > GDM_MAX_MAX_HIGH_OCC) max_high_occ = GDM_MAX_MAX_HIGH_OCC;
+					for (j = st, k = 0; j < en && k < max_high_occ; ++j, ++k) b[k] = (uint64_t)a[j].n << 32 | (uint32_t)j;
+					// the reference keeps the k smallest in a max-heap; the kept SET only depends on "replace the current
+					// maximum when a strictly smaller n arrives", so a linear scan for the maximum is equivalent
+					for (; j < en; ++j) {
+						int32_t mx = 0;
+						for (int32_t q = 1; q < k; ++q)
+							if (b[q] > b[mx]) mx = q;
+						if ((int32_t)a[j].n < (int32_t)(b[mx] >> 32)) b[mx] = (uint64_t)a[j].n << 32 | (uint32_t)j;
+					}
+					for (j = 0; j < k; ++j) a[(uint32_t)b[j]].flt = 1;
+				}
+				for (j = st; j < en; ++j) a[j].flt ^= 1;
+				for (j = st; j < en; ++j)
+					if ((int32_t)a[j].n > max_max_occ) a[j].flt = 1;
+			}
+			last0 = i;
+		}
+	}
+}
+
+// returns the number of kept seeds; *n_a = total occurrences of the kept seeds
+GDM_HD int gd_collect_matches2(const GdIdxView &I, const GdMini *mv, unsigned n_mv, int qlen, int max_occ, int max_max_occ,
+                               int dist, GdSeed *m, int64_t *n_a)
+{
+	int n_m0 = 0, n_m = 0;
+	for (unsigned i = 0; i < n_mv; ++i) {
+		uint64_t st;
+		const uint32_t t = gd_idx_get(I, mv[i].x >> 8, &st);
+		if (t == 0) continue;
+		GdSeed &q = m[n_m0++];
+		q.n = t, q.q_pos = (uint32_t)mv[i].y, q.start = (uint32_t)st, q.flt = 0;
+	}
+	if (dist > 0 && max_max_occ > max_occ) gd_seed_select(n_m0, m, qlen, max_occ, max_max_occ, dist);
+	else
+		for (int i = 0; i < n_m0; ++i)
+			if ((int32_t)m[i].n > max_occ) m[i].flt = 1;
+	*n_a = 0;
+	for (int i = 0; i < n_m0; ++i)
+		if (!m[i].flt) *n_a += m[i].n, m[n_m++] = m[i];
+	return n_m;
+}
+
+// ---- S6: collect_seed_hits (LR/map.c:861-955): occurrences -> loc_t on the forward / reverse strand -------------------
+struct GdLoc { uint64_t target; uint32_t query, pad; }; // loc_t (LR/map.c:738-741), 16-byte stride
+
+#define GDM_F_FOR_ONLY 0x100000
+#define GDM_F_REV_ONLY 0x200000
+
+GDM_HD void gd_seed_hits(const GdIdxView &I, const GdSeed *m, int n_m, int64_t flag, uint32_t tmp_extracted_len,
+                         GdLoc *a_for, GdLoc *a_rev, unsigned *n_for, unsigned *n_rev)
+{
+	unsigned nf = 0, nr = 0;
+	for (int i = 0; i < n_m; ++i) {
+		const GdSeed &q = m[i];
+		for (uint32_t k = 0; k < q.n; ++k) {
+			const uint64_t r = I.pos[(uint64_t)q.start + k];
+			if (flag & (GDM_F_FOR_ONLY | GDM_F_REV_ONLY)) { // skip_seed, LR/map.c:724-730
+				if ((r & 1) == (q.q_pos & 1)) { if (flag & GDM_F_REV_ONLY) continue; }
+				else if (flag & GDM_F_FOR_ONLY) continue;
+			}
+			const uint32_t qpos = q.q_pos >> 1;
+			const unsigned str = (unsigned)((r & 1) ^ (q.q_pos & 1));
+			uint32_t loc = (uint32_t)r >> 1;
+			const uint64_t chrom = r >> 32;
+			if (str) {
+				loc = loc + qpos;
+				a_rev[nr].target = chrom << 32 | loc, a_rev[nr].query = qpos, a_rev[nr].pad = 0, ++nr;
+			} else {
+				loc = loc + tmp_extracted_len - qpos;
+				a_for[nf].target = chrom << 32 | loc, a_for[nf].query = qpos, a_for[nf].pad = 0, ++nf;
+			}
+		}
+	}
+	*n_for = nf, *n_rev = nr;
+}
+
+// ---- S7: sort by target.  Any order among equal targets gives the same vote result (only min/max/count over a run
+// are used and ref_loc takes the -- equal -- target), so a plain key sort replaces the reference's run merge ---------
+GDM_HD GdLoc *gd_sort_locs(GdLoc *a, GdLoc *tmp, unsigned n)
+{
+	for (unsigned wd = 1; wd < n; wd <<= 1) {
+		for (unsigned lo = 0; lo < n; lo += 2 * wd) {
+			unsigned mid = lo + wd < n ? lo + wd : n, hi = lo + 2 * wd < n ? lo + 2 * wd : n;
+			unsigned i = lo, j = mid, o = lo;
+			while (i < mid && j < hi) tmp[o++] = a[j].target < a[i].target ? a[j++] : a[i++];
+			while (i < mid) tmp[o++] = a[i++];
+			while (j < hi) tmp[o++] = a[j++];
+		}
+		GdLoc *t = a; a = tmp; tmp = t;
+	}
+	return a;
+}
+
+// ---- V1: vote, LongReads (LR/map.c:1052-1180) -----------------------------------------------------------------------------
+struct GdVt { // vt_t (LR/map.c:1033-1045) without the alignment record
+	uint32_t chrom_id;
+	int32_t first_target_loc, last_target_loc;
+	uint32_t first_query_loc, last_query_loc;
+	uint32_t score;
+	uint32_t str;
+};
+
+GDM_HD uint64_t gd_vt_loc(const GdLoc &c, int str, int32_t tel)
+{
+	// (tmp_extracted_len - query) is evaluated in 32-bit unsigned arithmetic in the reference (int32 - uint32)
+	return str ? (c.target - c.query) : c.target - (uint64_t)(uint32_t)((uint32_t)tel - c.query);
+}
+
+GDM_HD void gd_vt_insert(GdVt *seqs, unsigned &out_len, unsigned max_n, unsigned counter, uint64_t ft, uint64_t lt, uint32_t fq,
+                         uint32_t lq, int str, bool &skip)
+{
+	skip = false;
+	if (out_len == max_n) {
+		if (seqs[out_len - 1].score >= counter) { skip = true; return; }
+	} else out_len++;
+	GdVt v;
+	v.chrom_id = (uint32_t)(ft >> 32), v.first_target_loc = (int32_t)(uint32_t)ft, v.last_target_loc = (int32_t)(uint32_t)lt;
+	v.first_query_loc = fq, v.last_query_loc = lq, v.str = (uint32_t)str, v.score = counter;
+	seqs[out_len - 1] = v;
+	for (unsigned k = out_len - 1; k > 0; k--) {
+		if (seqs[k].score > seqs[k - 1].score) { GdVt t = seqs[k]; seqs[k] = seqs[k - 1]; seqs[k - 1] = t; }
+		else break;
+	}
+}
+
+GDM_HD void gd_vote(const GdLoc *loc, unsigned len, int str, GdVt *seqs, unsigned *nb_seqs, uint32_t vt_distance, int32_t tel,
+                    unsigned max_n, uint32_t cov_thr)
+{
+	if (len == 0) return;
+	unsigned out_len = *nb_seqs, counter = 1;
+	uint64_t ft = gd_vt_loc(loc[0], str, tel), lt = ft, ref_loc = loc[0].target;
+	uint32_t fq = loc[0].query, lq = loc[0].query;
+	for (unsigned i = 1; i < len; i++) {
+		const GdLoc cur = loc[i];
+		if (cur.target - ref_loc <= vt_distance) {
+			counter++;
+			if (cur.query < fq) fq = cur.query, ref_loc = cur.target;
+			if (cur.query > lq) lq = cur.query;
+			const uint64_t l = gd_vt_loc(cur, str, tel);
+			if (l > lt) lt = l;
+			if (l < ft) ft = l;
+		} else {
+			if (lq - fq > cov_thr) {
+				bool skip;
+				gd_vt_insert(seqs, out_len, max_n, counter, ft, lt, fq, lq, str, skip);
+			}
+			ft = lt = gd_vt_loc(cur, str, tel);
+			fq = lq = cur.query, ref_loc = cur.target, counter = 1;
+		}
+	}
+	if (lq - fq > cov_thr) {
+		bool skip;
+		gd_vt_insert(seqs, out_len, max_n, counter, ft, lt, fq, lq, str, skip);
+	}
+	*nb_seqs = out_len;
+}
+
+// ---- V3: vote_2 (LR/map.c:1182-1271): best single run restricted to query interval (min,max) ------------------------------
+GDM_HD void gd_vote2(const GdLoc *loc, unsigned len, int str, GdVt *vt, uint32_t vt_distance, int32_t tel, uint32_t qmin, uint32_t qmax)
+{
+	if (len == 0) return;
+	GdVt best = *vt;
+	unsigned counter = 1;
+	uint64_t ft = gd_vt_loc(loc[0], str, tel), lt = ft, ref_loc = loc[0].target;
+	uint32_t fq = loc[0].query, lq = loc[0].query;
+	for (unsigned i = 1; i <= len; i++) {
+		if (i < len && loc[i].target - ref_loc <= vt_distance) {
+			const GdLoc cur = loc[i];
+			if (cur.query < qmax && cur.query > qmin) {
+				counter++;
+				if (cur.query < fq) fq = cur.query, ref_loc = cur.target;
+				if (cur.query > lq) lq = cur.query;
+				const uint64_t l = gd_vt_loc(cur, str, tel);
+				if (l > lt) lt = l;
+				if (l < ft) ft = l;
+			}
+		} else {
+			if (counter > best.score && lq < qmax && fq > qmin) {
+				best.chrom_id = (uint32_t)(ft >> 32), best.first_target_loc = (int32_t)(uint32_t)ft, best.last_target_loc = (int32_t)(uint32_t)lt;
+				best.first_query_loc = fq, best.last_query_loc = lq, best.str = (uint32_t)str, best.score = counter;
+			}
+			if (i < len) {
+				const GdLoc cur = loc[i];
+				ft = lt = gd_vt_loc(cur, str, tel);
+				fq = lq = cur.query, ref_loc = cur.target, counter = 1;
+			}
+		}
+	}
+	*vt = best;
+}
+
+// ---- V1+G1 (first half): the candidate list of one long read, LR/map.c:1342-1445 ---------------------------------------------
+struct GdLrVoteOpt {
+	uint32_t vt_dis, vt_nb_loc, bw;
+	float vt_cov, vt_f, vt_df1, vt_df2;
+	int32_t k;
+};
+
+#define GDM_MAX_VT 16 // vt_nb_loc + 2 must fit
+
+// seqs[] must hold vt_nb_loc+2 entries.  Returns the number of candidates (0: unmapped).
+GDM_HD unsigned gd_lr_candidates(const GdLoc *a_for, unsigned n_for, const GdLoc *a_rev, unsigned n_rev, uint32_t qlen_sum,
+                                 int32_t tel, const GdLrVoteOpt &O, GdVt *seqs)
+{
+	const uint32_t cov_thr = (uint32_t)((float)qlen_sum * O.vt_cov); // :1342
+	unsigned nb = 0;
+	gd_vote(a_for, n_for, 0, seqs, &nb, O.vt_dis, tel, O.vt_nb_loc, cov_thr);
+	gd_vote(a_rev, n_rev, 1, seqs, &nb, O.vt_dis, tel, O.vt_nb_loc, cov_thr);
+	if (nb == 0) return 0;
+	// density filter, :1355-1363 -- bug-compatible: the copy goes the wrong way (seqs[i] = seqs[nb_df])
+	unsigned nb_df = 0;
+	for (unsigned i = 0; i < nb; i++)
+		if ((float)seqs[i].score > O.vt_df1 * (float)(seqs[i].last_target_loc - seqs[i].first_target_loc)) {
+			seqs[i] = seqs[nb_df];
+			nb_df++;
+		}
+	nb = nb_df;
+	if (nb == 0) return 0;
+	uint32_t qrstart = qlen_sum, qrend = 0;
+	const unsigned filt = (unsigned)((float)seqs[0].score * O.vt_f); // :1377
+	for (unsigned i = 0; i < nb; i++) {
+		if (seqs[i].score < filt) { nb = i; break; }
+		seqs[i].first_query_loc -= (uint32_t)(O.k - 1);
+		seqs[i].first_target_loc -= (O.k - 1);
+		if ((double)(uint32_t)(seqs[i].last_query_loc - seqs[i].first_query_loc) + 0.5 * (double)O.bw <
+		    (double)(int32_t)(seqs[i].last_target_loc - seqs[i].first_target_loc))
+			seqs[i].last_target_loc = (int32_t)((double)(uint32_t)(seqs[i].first_target_loc + seqs[i].last_query_loc - seqs[i].first_query_loc) + 0.5 * (double)O.bw);
+		if (seqs[i].first_query_loc < qrstart) qrstart = seqs[i].first_query_loc;
+		if (seqs[i].last_query_loc > qrend) qrend = seqs[i].last_query_loc;
+	}
+	// second round on an uncovered read head / tail, :1403-1445
+	for (int side = 0; side < 2; ++side) {
+		const bool go = side == 0 ? qrstart > cov_thr : qlen_sum - qrend > cov_thr;
+		if (!go) continue;
+		GdVt v2;
+		v2.chrom_id = 0, v2.first_target_loc = v2.last_target_loc = 0, v2.first_query_loc = v2.last_query_loc = 0, v2.score = 0, v2.str = 0;
+		const uint32_t mn = side == 0 ? 0 : qrend, mx = side == 0 ? qrstart : qlen_sum;
+		gd_vote2(a_for, n_for, 0, &v2, O.vt_dis, tel, mn, mx);
+		gd_vote2(a_rev, n_rev, 1, &v2, O.vt_dis, tel, mn, mx);
+		v2.first_query_loc -= (uint32_t)(O.k - 1);
+		v2.first_target_loc -= (O.k - 1);
+		if ((float)v2.score > O.vt_df2 * (float)(v2.last_target_loc - v2.first_target_loc)) {
+			if ((double)(uint32_t)(v2.last_query_loc - v2.first_query_loc) + 0.5 * (double)O.bw <
+			    (double)(int32_t)(v2.last_target_loc - v2.first_target_loc))
+				v2.last_target_loc = (int32_t)((double)(uint32_t)(v2.first_target_loc + v2.last_query_loc - v2.first_query_loc) + 0.5 * (double)O.bw);
+			seqs[nb++] = v2;
+		}
+	}
+	return nb;
+}

@@ -1,0 +1,172 @@
+"""ctypes binding of the B1 part of include/gdiet_hip.h: device index + per-read mapping batches + SAM records.
+
+Mirrors the reference's call shape: ``Mapper(ctx, ref_names, ref_seqs, preset_options)`` stands for
+``mm_idx_gen`` + ``mm_mapopt_update``; ``Mapper.map(reads)`` for one ``kt_for(worker_for)`` pass over a batch
+(reference map.c, step 1 of worker_pipeline); ``Mapper.sam(...)`` for ``mm_write_sam3``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .hip_abi import GdietError, load_library
+
+F_NO_PRINT_2ND = 0x4000
+
+
+class MapOpt(C.Structure):
+    _fields_ = [("flag", C.c_int64), ("a", C.c_int32), ("b", C.c_int32), ("q", C.c_int32), ("e", C.c_int32), ("q2", C.c_int32),
+                ("e2", C.c_int32), ("bw", C.c_uint32), ("min_dp_max", C.c_int32), ("best_n", C.c_int32), ("q_occ_frac", C.c_float),
+                ("mid_occ", C.c_int32), ("max_max_occ", C.c_int32), ("occ_dist", C.c_int32), ("max_frag_len", C.c_int32),
+                ("vt_dis", C.c_uint32), ("vt_nb_loc", C.c_uint32), ("vt_cov", C.c_float), ("vt_f", C.c_float), ("vt_df1", C.c_float),
+                ("vt_df2", C.c_float), ("max_max_gap", C.c_uint32), ("max_min_gap", C.c_uint32), ("max_seeds", C.c_float)]
+
+
+class Reg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("id", "cnt", "rid", "score", "qs", "qe", "rs", "re", "parent", "subsc", "mlen", "blen")] + \
+               [("mapq", C.c_uint32), ("rev", C.c_uint32), ("sam_pri", C.c_uint32), ("dp_score", C.c_int32), ("dp_max", C.c_int32),
+                ("n_ambi", C.c_uint32), ("n_cigar", C.c_uint32), ("cigar", C.POINTER(C.c_uint32))]
+
+
+# the canonical command lines of the reference's README, as option values.
+# idx: k, w, pattern; min/max_mid_occ: the clamp mm_mapopt_update applies (options.c:64-70, presets :45/:106)
+PRESETS = {
+    "hifi": dict(k=19, w=19, Z="10", W=2, a=1, b=4, q=6, e=2, q2=26, e2=1, bw=1000, min_dp_max=400, best_n=1, max_seeds=0.2,
+                 vt_dis=650, vt_nb_loc=5, vt_df1=0.0106, vt_df2=0.2, vt_cov=0.04, vt_f=0.04, max_min_gap=4000, max_max_gap=50000,
+                 occ_dist=500, min_mid_occ=50, max_mid_occ=500, flag=0),
+    "ont": dict(k=15, w=10, Z="10", W=2, a=2, b=4, q=4, e=2, q2=24, e2=1, bw=1300, min_dp_max=35000, best_n=1, max_seeds=0.2,
+                vt_dis=1000, vt_nb_loc=3, vt_df1=0.007, vt_df2=0.007, vt_cov=0.3, vt_f=0.04, max_min_gap=4000, max_max_gap=50000,
+                occ_dist=500, min_mid_occ=10, max_mid_occ=1000000, flag=0),
+}
+
+
+def _bind(lib):
+    if getattr(lib, "_map_bound", False):
+        return
+    vp = C.c_void_p
+    cpp = C.POINTER(C.c_char_p)
+    i32p, u32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    lib.gdiet_hip_index_build.argtypes = [vp, C.POINTER(vp), C.c_int, cpp, cpp, u32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    lib.gdiet_hip_index_destroy.argtypes = [vp, vp]
+    lib.gdiet_hip_index_destroy.restype = None
+    lib.gdiet_hip_index_cal_max_occ.argtypes = [vp, C.c_float]
+    lib.gdiet_hip_index_cal_max_occ.restype = C.c_int32
+    lib.gdiet_hip_index_n_keys.argtypes = [vp]
+    lib.gdiet_hip_index_n_keys.restype = C.c_uint64
+    lib.gdiet_hip_map_batch.argtypes = [vp, vp, C.POINTER(MapOpt), C.c_int, cpp, i32p, i32p, C.POINTER(C.POINTER(Reg))]
+    lib.gdiet_hip_free_regs.argtypes = [C.c_int, i32p, C.POINTER(C.POINTER(Reg))]
+    lib.gdiet_hip_free_regs.restype = None
+    lib.gdiet_hip_batch_upload.argtypes = [vp, C.POINTER(vp), C.c_int, cpp, i32p]
+    lib.gdiet_hip_map_uploaded.argtypes = [vp, vp, C.POINTER(MapOpt), vp, i32p, C.POINTER(C.POINTER(Reg))]
+    lib.gdiet_hip_batch_destroy.argtypes = [vp, vp]
+    lib.gdiet_hip_batch_destroy.restype = None
+    lib.gdiet_hip_map_stage_seconds.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.gdiet_hip_set_host_threads.argtypes = [vp, C.c_int]
+    lib.gdiet_hip_sam_record.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(Reg), C.c_int32, C.c_int32,
+                                         C.c_int64, C.c_char_p, C.c_size_t]
+    lib.gdiet_hip_sam_record.restype = C.c_size_t
+    lib._map_bound = True
+
+
+class MapResult:
+    """regs of one batch; frees the C arrays when dropped"""
+
+    def __init__(self, lib, n, n_regs, regs):
+        self.lib, self.n, self.n_regs, self.regs = lib, n, n_regs, regs
+
+    def __del__(self):
+        try:
+            self.lib.gdiet_hip_free_regs(self.n, self.n_regs, self.regs)
+        except Exception:
+            pass
+
+
+class Mapper:
+    def __init__(self, ctx, names, seqs, preset="hifi", n_threads=0, **overrides):
+        self.ctx, self.lib = ctx, load_library()
+        _bind(self.lib)
+        p = dict(PRESETS[preset])
+        p.update(overrides)
+        self.p = p
+        n = len(seqs)
+        seqs = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+        names = [s if isinstance(s, bytes) else s.encode() for s in names]
+        self.names = [x.decode() for x in names]
+        a_names = (C.c_char_p * n)(*names)
+        a_seqs = (C.c_char_p * n)(*seqs)
+        lens = np.array([len(s) for s in seqs], np.uint32)
+        self._idx = C.c_void_p()
+        rc = self.lib.gdiet_hip_index_build(ctx._h, C.byref(self._idx), n, a_names, a_seqs, lens.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            p["k"], p["w"], p["Z"].encode(), p["W"], n_threads)
+        ctx._check(rc)
+        # mm_mapopt_update (reference options.c:64-76)
+        mid = p.get("mid_occ", 0)
+        if mid <= 0:
+            mid = self.lib.gdiet_hip_index_cal_max_occ(self._idx, C.c_float(2e-4))
+            mid = max(mid, p["min_mid_occ"])
+            if p["max_mid_occ"] > p["min_mid_occ"]:
+                mid = min(mid, p["max_mid_occ"])
+        self.mid_occ = mid
+        self.opt = MapOpt(flag=p["flag"], a=p["a"], b=p["b"], q=p["q"], e=p["e"], q2=p["q2"], e2=p["e2"], bw=p["bw"],
+                          min_dp_max=p["min_dp_max"], best_n=p["best_n"], q_occ_frac=0.01, mid_occ=mid, max_max_occ=4095,
+                          occ_dist=p["occ_dist"], max_frag_len=0, vt_dis=p["vt_dis"], vt_nb_loc=p["vt_nb_loc"], vt_cov=p["vt_cov"],
+                          vt_f=p["vt_f"], vt_df1=p["vt_df1"], vt_df2=p["vt_df2"], max_max_gap=p["max_max_gap"],
+                          max_min_gap=p["max_min_gap"], max_seeds=p["max_seeds"])
+
+    def close(self):
+        if self._idx:
+            self.lib.gdiet_hip_index_destroy(self.ctx._h, self._idx)
+            self._idx = C.c_void_p()
+
+    def n_keys(self):
+        return self.lib.gdiet_hip_index_n_keys(self._idx)
+
+    def _arrays(self, reads):
+        n = len(reads)
+        reads = [s if isinstance(s, bytes) else s.encode() for s in reads]
+        return n, reads, (C.c_char_p * n)(*reads), np.array([len(s) for s in reads], np.int32)
+
+    def map(self, reads):
+        n, reads, arr, lens = self._arrays(reads)
+        n_regs = (C.c_int32 * n)()
+        regs = (C.POINTER(Reg) * n)()
+        rc = self.lib.gdiet_hip_map_batch(self.ctx._h, self._idx, C.byref(self.opt), n, arr, lens.ctypes.data_as(C.POINTER(C.c_int32)), n_regs, regs)
+        self.ctx._check(rc)
+        return MapResult(self.lib, n, n_regs, regs)
+
+    def upload(self, reads):
+        n, reads, arr, lens = self._arrays(reads)
+        h = C.c_void_p()
+        self.ctx._check(self.lib.gdiet_hip_batch_upload(self.ctx._h, C.byref(h), n, arr, lens.ctypes.data_as(C.POINTER(C.c_int32))))
+        return (h, n)
+
+    def map_uploaded(self, batch):
+        h, n = batch
+        n_regs = (C.c_int32 * n)()
+        regs = (C.POINTER(Reg) * n)()
+        self.ctx._check(self.lib.gdiet_hip_map_uploaded(self.ctx._h, self._idx, C.byref(self.opt), h, n_regs, regs))
+        return MapResult(self.lib, n, n_regs, regs)
+
+    def free_batch(self, batch):
+        self.lib.gdiet_hip_batch_destroy(self.ctx._h, batch[0])
+
+    def stage_seconds(self):
+        out = (C.c_double * 6)()
+        self.lib.gdiet_hip_map_stage_seconds(self.ctx._h, out)
+        return list(out)
+
+    def sam(self, res, i, qname, seq, qual=None):
+        """SAM lines of read i of a MapResult, as the reference's output step prints them (map.c step 2)."""
+        lines = []
+        seq_b = seq if isinstance(seq, bytes) else seq.encode()
+        qual_b = None if qual is None else (qual if isinstance(qual, bytes) else qual.encode())
+        n = res.n_regs[i]
+        buf = C.create_string_buffer(4 * len(seq_b) + 4096 + 64 * max(1, sum(res.regs[i][j].n_cigar for j in range(n))))
+        idxs = list(range(n)) if n > 0 else [-1]
+        for j in idxs:
+            if j >= 0 and (self.opt.flag & F_NO_PRINT_2ND) and res.regs[i][j].id != res.regs[i][j].parent:
+                continue
+            need = self.lib.gdiet_hip_sam_record(self._idx, qname.encode(), seq_b, qual_b, len(seq_b), res.regs[i], n, j, self.opt.flag, buf, len(buf))
+            if need >= len(buf):
+                raise GdietError("SAM buffer too small")
+            lines.append(buf.value.decode())
+        return lines

@@ -104,6 +104,82 @@ int gdiet_hip_set_kernel_mode(gdiet_ctx *ctx, int mode);
  * most recent *_dev / host batch; only valid after the stream has been synchronised. */
 int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *backtrack_ms);
 
+/* ---- B1: the per-read mapping path for a whole batch of reads (LongReads variant) -----------------------------
+ * Replaces step 1 of worker_pipeline -- kt_for(n_threads, worker_for, ...) -> mm_map_frag() per read
+ * (LR/map.c:2132-2137 -> :1975-2022 -> :1273-1940): sketch2/get_shift/sketch3, seed filter + collect, hit sort,
+ * vote/vote_2, candidate geometry, exact-match / ksw_extd2 / backtrack, mm_update_extra, concatenate_cigars,
+ * mm_set_sam_params.  The seeding/voting stages and the DP run on the GPU; geometry and CIGAR post-processing
+ * run on host threads inside this library (they need the float/double comparisons and the bug-compatible
+ * control flow of the reference).
+ */
+
+/* device-resident index: the flat mirror of mm_idx_t (LR/minimap.h:79-96, LR/index.c:29-34,84-100) */
+typedef struct gdiet_index gdiet_index;
+
+/* Build the index from nt ASCII sequences with this library's own builder (same minimizers, same position order
+ * as mm_idx_gen of GDiet_avx: LR/index.c:306-412, LR/sketch.c:156/1577) and upload it.  pattern/pattern_len = -Z/-W. */
+int gdiet_hip_index_build(gdiet_ctx *ctx, gdiet_index **idx, int n_seq, const char *const *names,
+                          const char *const *seqs, const uint32_t *lens, int k, int w, const char *pattern,
+                          int pattern_len, int n_threads);
+/* Upload an index that the caller already holds in flat form -- what a reference-side stub produces by walking
+ * mm_idx_t::B[]: keys[i] = minimizer hash (x>>8), cnt[i] its number of occurrences, pos = the
+ * occurrence lists (y values, each list sorted ascending) concatenated in key order; S = mm_idx_t::S. */
+int gdiet_hip_index_import(gdiet_ctx *ctx, gdiet_index **idx, int k, int w, const char *pattern, int pattern_len,
+                           int n_seq, const char *const *names, const uint32_t *lens, const uint64_t *offsets,
+                           const uint32_t *S, uint64_t n_keys, const uint64_t *keys, const uint32_t *cnt,
+                           const uint64_t *pos);
+void gdiet_hip_index_destroy(gdiet_ctx *ctx, gdiet_index *idx);
+/* mm_idx_cal_max_occ (LR/index.c:190-210) */
+int32_t gdiet_hip_index_cal_max_occ(const gdiet_index *idx, float frac);
+uint64_t gdiet_hip_index_n_keys(const gdiet_index *idx);
+
+/* the fields of mm_mapopt_t (LR/minimap.h:145-214) this path reads; fill them from the reference's struct */
+typedef struct {
+	int64_t flag;                 /* MM_F_* bits; only NO_PRINT_2ND, SR, FRAG_MODE, FOR_ONLY, REV_ONLY are interpreted */
+	int32_t a, b, q, e, q2, e2;
+	uint32_t bw;
+	int32_t min_dp_max, best_n;
+	float q_occ_frac;
+	int32_t mid_occ, max_max_occ, occ_dist, max_frag_len;
+	uint32_t vt_dis, vt_nb_loc;
+	float vt_cov, vt_f, vt_df1, vt_df2;
+	uint32_t max_max_gap, max_min_gap;
+	float max_seeds;
+} gdiet_mapopt_t;
+
+/* one alignment record: mm_reg1_t + mm_extra_t (LR/minimap.h:105-131) flattened */
+typedef struct {
+	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, mlen, blen;
+	uint32_t mapq, rev, sam_pri;
+	int32_t dp_score, dp_max;
+	uint32_t n_ambi, n_cigar;
+	uint32_t *cigar;              /* malloc'd by the library */
+} gdiet_reg_t;
+
+/* Map n_reads single-segment reads (ASCII sequences).  On return regs[i] is a malloc'd array of n_regs[i] records
+ * (NULL when n_regs[i] == 0, as LR/map.c:1915), in the order mm_map_frag leaves them.  Free with gdiet_hip_free_regs. */
+int gdiet_hip_map_batch(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, int n_reads,
+                        const char *const *seqs, const int32_t *lens, int32_t *n_regs, gdiet_reg_t **regs);
+void gdiet_hip_free_regs(int n_reads, int32_t *n_regs, gdiet_reg_t **regs);
+
+/* Two-step form for measurements: stage a batch in HBM once, then map it (repeatedly).  Only the second call belongs
+ * to a timed region whose inputs are "already resident in HBM". */
+typedef struct gdiet_read_batch gdiet_read_batch;
+int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **batch, int n_reads, const char *const *seqs, const int32_t *lens);
+int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, gdiet_read_batch *batch,
+                           int32_t *n_regs, gdiet_reg_t **regs);
+void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *batch);
+/* seconds spent in the stages of the most recent map call: [0] seed kernel, [1] vote kernel, [2] host geometry,
+ * [3] gather + DP + backtrack kernels, [4] host post-processing, [5] transfers/other */
+int gdiet_hip_map_stage_seconds(const gdiet_ctx *ctx, double out[6]);
+/* number of host threads used for geometry / CIGAR post-processing (default: hardware concurrency) */
+int gdiet_hip_set_host_threads(gdiet_ctx *ctx, int n);
+
+/* One SAM record exactly as mm_write_sam3 prints it for a single-segment read (LR/format.c:412-599); reg_idx < 0 writes
+ * the unmapped record.  Returns the number of bytes needed (excluding the terminating NUL); writes at most cap bytes. */
+size_t gdiet_hip_sam_record(const gdiet_index *idx, const char *qname, const char *seq, const char *qual, int32_t l_seq,
+                            const gdiet_reg_t *regs, int32_t n_regs, int32_t reg_idx, int64_t opt_flag, char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

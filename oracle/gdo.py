@@ -11,6 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 NEG_INF = -0x40000000
+EZ_AVX512_SC = 0x10000
 EZ_SCORE_ONLY, EZ_RIGHT, EZ_GENERIC_SC, EZ_APPROX_MAX, EZ_APPROX_DROP, EZ_EXTZ_ONLY, EZ_REV_CIGAR = 1, 2, 4, 8, 0x10, 0x40, 0x80
 
 

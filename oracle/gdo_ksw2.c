@@ -120,7 +120,19 @@ static void fill_scores(int flag, int st0, int en0, u8t *s, const u8t *sf, const
                         i8 sc_mch, i8 sc_mis, i8 sc_N)
 {
 	int t, i;
-	if (!(flag & GDO_EZ_GENERIC_SC)) {
+	if (flag & GDO_EZ_AVX512_SC) {
+		/* the AVX-512 port (SR/ksw2_extd2_avx.c:183-209,310-313): query N is stored as 8, the score is a 16-entry
+		 * table indexed by the low nibble of target ^ query: 0 match, 1-3 mismatch, 4-12 sc_N, 13-15 zero.  Same as the
+		 * SSE rule for bytes 0..4, different for any other byte (the reverse-complemented N = 7 of LR/map.c:1634). */
+		for (t = st0; t <= en0; t += 16) {
+			u8t sq[16], st[16];
+			memcpy(sq, sf + t, 16), memcpy(st, qrr + t, 16);
+			for (i = 0; i < 16; ++i) {
+				const int x = (sq[i] ^ (st[i] == 4 ? 8 : st[i])) & 15;
+				s[t + i] = (u8t)(x == 0 ? sc_mch : x <= 3 ? sc_mis : x <= 12 ? sc_N : 0);
+			}
+		}
+	} else if (!(flag & GDO_EZ_GENERIC_SC)) {
 		for (t = st0; t <= en0; t += 16) {
 			u8t sq[16], st[16];
 			memcpy(sq, sf + t, 16), memcpy(st, qrr + t, 16); /* loads complete before the store */

@@ -34,6 +34,8 @@ extern "C" {
 #define GDO_EZ_APPROX_DROP 0x10
 #define GDO_EZ_EXTZ_ONLY   0x40
 #define GDO_EZ_REV_CIGAR   0x80
+/* ours: score cells the way ksw_extd2_avx512 does (see fill_scores); only differs from the SSE rule for bytes outside 0..4 */
+#define GDO_EZ_AVX512_SC   0x10000
 
 /* mirrors ksw_extz_t, SR/ksw2.h:31-40 (plain ints instead of bit-fields) */
 typedef struct {

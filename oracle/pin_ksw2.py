@@ -98,6 +98,7 @@ def main():
 
     n_bad_sse = n_bad_avx = n_sse_vs_avx = 0
     gold = []
+    gold_avx = []
     for idx, (tag, q, t, preset, w, zdrop, end_bonus, flag) in enumerate(cases(rng, args.fuzz)):
         a, b, go, ge, go2, ge2 = gdo.PRESETS[preset]
         mat = gdo.score_matrix(a, b)
@@ -110,13 +111,25 @@ def main():
                 print("MISMATCH oracle vs SSE", idx, tag, len(q), len(t), preset, w, flag, zdrop,
                       {k: (o[k], r[k]) for k in keys if o[k] != r[k]}, len(o["cigar"]), len(r["cigar"]))
         if flag == gdo.EZ_APPROX_MAX:  # the AVX-512 port is only used (and only valid) in the live-path mode
-            v = gdo.ref_extd2(ref, q, t, mat, go, ge, go2, ge2, w, zdrop, end_bonus, flag, fn="ksw_extd2_avx512")
-            if not gdo.same(o, v):
+            # the parity target's kernel; the oracle reproduces its score table with GDO_EZ_AVX512_SC.  Every third
+            # pair gets some query bytes 7 (= N of a reverse-complemented read, LR/map.c:1634), where SSE and AVX-512 differ.
+            q7 = q.copy()
+            if idx % 3 == 0 and len(q7) > 4:
+                pos7 = rng.integers(0, len(q7), size=max(1, len(q7) // 100))
+                q7[pos7] = 7
+                run = int(rng.integers(0, len(q7) - 3))
+                q7[run:run + int(rng.integers(1, 40))] = 7
+            v = gdo.ref_extd2(ref, q7, t, mat, go, ge, go2, ge2, w, zdrop, end_bonus, flag, fn="ksw_extd2_avx512")
+            o7 = gdo.oracle_extd2(ora, q7, t, mat, go, ge, go2, ge2, w, zdrop, end_bonus, flag | gdo.EZ_AVX512_SC)
+            if not gdo.same(o7, v):
                 n_bad_avx += 1
-            if not gdo.same(r, v):
+                if n_bad_avx <= 5:
+                    print("MISMATCH oracle(AVX512_SC) vs ksw_extd2_avx512", idx, tag, len(q), len(t), preset, w, o7["score"], v["score"])
+            r7 = gdo.ref_extd2(ref, q7, t, mat, go, ge, go2, ge2, w, zdrop, end_bonus, flag)
+            if not gdo.same(r7, v):
                 n_sse_vs_avx += 1
-                if n_sse_vs_avx <= 5:
-                    print("NOTE SSE vs AVX512 differ", idx, tag, len(q), len(t), preset, w, r["score"], v["score"])
+            if idx < 360:
+                gold_avx.append((q7, t, preset, w, zdrop, end_bonus, flag, v))
         # extz2 (single affine) on the same pair
         oz = gdo.oracle_extz2(ora, q, t, mat, go, ge, w, zdrop, end_bonus, flag)
         rz = gdo.ref_extz2(ref, q, t, mat, go, ge, w, zdrop, end_bonus, flag)
@@ -141,7 +154,7 @@ def main():
             n_bad_em += 1
         if i < 60:
             em.append((q, t, gdo.ref_exact_match(ref, q, t, mat)))
-    print("pairs=%d oracle_vs_sse_mismatch=%d oracle_vs_avx512_mismatch=%d sse_vs_avx512_differ=%d exact_match_mismatch=%d"
+    print("pairs=%d oracle_vs_sse_mismatch=%d oracle_vs_avx512_mismatch=%d sse_vs_avx512_differ_on_byte7_inputs=%d exact_match_mismatch=%d"
           % (args.fuzz, n_bad_sse, n_bad_avx, n_sse_vs_avx, n_bad_em))
 
     if args.write_golden:
@@ -161,6 +174,14 @@ def main():
                                                   "mte_q", "reach_end")] for g in gold], np.int64)
             np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), q=qs, qo=qo, t=ts, to=to, params=params,
                                 cigar_bytes=cg, cigar_off=co, scalars=scal)
+        qs7, qo7 = pack([g[0] for g in gold_avx])
+        ts7, to7 = pack([g[1] for g in gold_avx])
+        params7 = np.array([[("sr", "hifi", "ont").index(g[2]), g[3], g[4], g[5], g[6]] for g in gold_avx], np.int32)
+        cg7, co7 = pack([g[7]["cigar"].view(np.uint8) for g in gold_avx])
+        scal7 = np.array([[g[7][f] for f in ("score", "zdropped", "max", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q",
+                                             "reach_end")] for g in gold_avx], np.int64)
+        np.savez_compressed(os.path.join(GOLDEN, "ksw2_extd2_avx512.npz"), q=qs7, qo=qo7, t=ts7, to=to7, params=params7,
+                            cigar_bytes=cg7, cigar_off=co7, scalars=scal7)
         eq, eqo = pack([e[0] for e in em])
         et, eto = pack([e[1] for e in em])
         np.savez_compressed(os.path.join(GOLDEN, "exact_match.npz"), q=eq, qo=eqo, t=et, to=eto,

@@ -1,0 +1,211 @@
+// CPU test driver (test infrastructure): runs the product's host/device-shared stage code (map_stages.h) on the HOST,
+// with the CPU oracle's ksw_extd2 standing in for the HIP DP kernel, through the product's host post-processing
+// (map_host.h) and prints SAM records.  tests/test_map_host.py diffs that against the reference binary
+// (oracle/_ref/gdiet_lr_avx) and against the committed golden SAM.  This is how the seeding/voting/geometry/
+// post-processing code is validated in a container without a GPU; the GPU path replaces only the executors.
+//
+//   map_host_main [-x map-hifi|map-ont] [-k K] [-w W] [-Z pat] [-W n] [-i f] [-r bw] [-s min_dp] [-N n] [--vt_dis=..] ... ref.fa reads.fq
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#define __host__
+#define __device__
+#include "map_index.h"
+#include "map_host.h"
+#include "map_stages.h"
+#include "gdo_ksw2.h"
+
+static bool read_fastx(const char *fn, std::vector<std::string> &names, std::vector<std::string> &seqs, std::vector<std::string> *quals)
+{
+	FILE *f = fopen(fn, "r");
+	if (!f) return false;
+	char *line = 0;
+	size_t cap = 0;
+	ssize_t l;
+	int state = 0; // 0: expect header; 1: fasta seq; 2: fastq seq; 3: fastq '+'; 4: fastq qual
+	while ((l = getline(&line, &cap, f)) >= 0) {
+		while (l > 0 && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
+		if (state == 0 || state == 1) {
+			if (line[0] == '>' || line[0] == '@') {
+				std::string nm(line + 1);
+				size_t sp = nm.find_first_of(" \t");
+				if (sp != std::string::npos) nm.resize(sp);
+				names.push_back(nm), seqs.emplace_back();
+				if (quals) quals->emplace_back();
+				state = line[0] == '>' ? 1 : 2;
+			} else if (state == 1) seqs.back() += line;
+		} else if (state == 2) {
+			if (line[0] == '+') state = 4;
+			else seqs.back() += line;
+		} else if (state == 4) {
+			if (quals) quals->back() += line;
+			if (!quals || quals->back().size() >= seqs.back().size()) state = 0;
+		}
+	}
+	free(line);
+	fclose(f);
+	return true;
+}
+
+int main(int argc, char **argv)
+{
+	GdMapOpt O;
+	// mm_mapopt_init defaults (LR/options.c:13-62) + the GDiet-forced values (LR/main.c:169-185)
+	O.a = 2, O.b = 4, O.q = 4, O.e = 2, O.q2 = 24, O.e2 = 1, O.bw = 1000, O.best_n = 5, O.k = 15, O.w = 10;
+	int min_mid_occ = 10, max_mid_occ = 1000000;
+	float mid_occ_frac = 2e-4f;
+	const char *Z = "11";
+	int W = 2;
+	O.flag = GD_F_NO_PRINT_2ND * 0;
+	std::vector<const char *> pos;
+	bool preset_seen = false;
+	for (int pass = 0; pass < 2; ++pass) { // pass 0: -x only (as the reference does), pass 1: everything else
+		for (int i = 1; i < argc; ++i) {
+			std::string a = argv[i];
+			auto val = [&](const char *name) -> const char * { // --name=value or --name value
+				std::string p = std::string("--") + name;
+				if (a.compare(0, p.size() + 1, p + "=") == 0) return argv[i] + p.size() + 1;
+				if (a == p && i + 1 < argc) return argv[++i];
+				return nullptr;
+			};
+			const char *v;
+			if (a == "-x") {
+				const char *p = argv[++i];
+				if (pass == 0) {
+					preset_seen = true;
+					if (!strcmp(p, "map-hifi")) { O.k = 19, O.w = 19, O.a = 1, O.b = 4, O.q = 6, O.q2 = 26, O.e = 2, O.e2 = 1, O.occ_dist = 500, min_mid_occ = 50, max_mid_occ = 500; }
+					else if (!strcmp(p, "map-ont")) {}
+					else { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
+				}
+			} else if (a[0] == '-' && a.size() > 2 && a[1] == 'a' && a[2] == 'x') { // -ax <preset>
+				const char *p = argv[++i];
+				if (pass == 0) {
+					preset_seen = true;
+					if (!strcmp(p, "map-hifi")) { O.k = 19, O.w = 19, O.a = 1, O.b = 4, O.q = 6, O.q2 = 26, O.e = 2, O.e2 = 1, O.occ_dist = 500, min_mid_occ = 50, max_mid_occ = 500; }
+					else if (!strcmp(p, "map-ont")) {}
+					else { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
+				}
+			} else if (a == "-t" || a == "-o") ++i;
+			else if (a == "-a") {}
+			else if (a == "-k") { v = argv[++i]; if (pass) O.k = atoi(v); }
+			else if (a == "-w") { v = argv[++i]; if (pass) O.w = atoi(v); }
+			else if (a == "-Z") { v = argv[++i]; if (pass) Z = v; }
+			else if (a == "-W") { v = argv[++i]; if (pass) W = atoi(v); }
+			else if (a == "-i") { v = argv[++i]; if (pass) { O.max_seeds = (float)strtod(v, 0); if (O.max_seeds < 0) O.max_seeds = 0.1f; } }
+			else if (a == "-r") { v = argv[++i]; if (pass) O.bw = (uint32_t)strtoul(v, 0, 10); }
+			else if (a == "-s") { v = argv[++i]; if (pass) O.min_dp_max = atoi(v); }
+			else if (a == "-N") { v = argv[++i]; if (pass) O.best_n = atoi(v); }
+			else if (a.compare(0, 2, "-F") == 0) { if (a.size() == 2) ++i; }
+			else if ((v = val("vt_dis"))) { if (pass) O.vt_dis = (uint32_t)strtoul(v, 0, 10); }
+			else if ((v = val("vt_nb_loc"))) { if (pass) O.vt_nb_loc = (uint32_t)strtoul(v, 0, 10); }
+			else if ((v = val("vt_cov"))) { if (pass) O.vt_cov = strtof(v, 0); }
+			else if ((v = val("vt_f"))) { if (pass) O.vt_f = strtof(v, 0); }
+			else if ((v = val("vt_df1"))) { if (pass) O.vt_df1 = strtof(v, 0); }
+			else if ((v = val("vt_df2"))) { if (pass) O.vt_df2 = strtof(v, 0); }
+			else if ((v = val("max_min_gap"))) { if (pass) O.max_min_gap = (uint32_t)strtoul(v, 0, 10); }
+			else if ((v = val("max_max_gap"))) { if (pass) O.max_max_gap = (uint32_t)strtoul(v, 0, 10); }
+			else if ((v = val("sort")) || (v = val("frag"))) {}
+			else if ((v = val("secondary"))) { if (pass) { if (!strcmp(v, "yes")) O.flag &= ~(int64_t)GD_F_NO_PRINT_2ND; else O.flag |= GD_F_NO_PRINT_2ND; } }
+			else if (a[0] == '-') { fprintf(stderr, "unsupported option %s\n", a.c_str()); return 2; }
+			else if (pass) pos.push_back(argv[i]);
+		}
+		if (pass == 0) { // GDiet-forced values after the preset (LR/main.c:169-185)
+			O.max_seeds = 0.1f, O.vt_dis = 100, O.vt_nb_loc = 3, O.vt_cov = 0.03f, O.vt_df1 = 0.01f, O.vt_df2 = 0.01f, O.vt_f = 0.05f;
+			O.max_max_gap = 50000, O.min_dp_max = 40, O.max_min_gap = 4000;
+		}
+	}
+	(void)preset_seen;
+	if (pos.size() < 2) { fprintf(stderr, "usage: map_host_main [options] ref.fa reads.fq\n"); return 2; }
+	if (!gd_pattern_init(O.pat, Z, W)) { fprintf(stderr, "bad pattern\n"); return 2; }
+	std::vector<std::string> rn, rs, qn, qs, qq;
+	if (!read_fastx(pos[0], rn, rs, nullptr) || !read_fastx(pos[1], qn, qs, &qq)) { fprintf(stderr, "cannot read input\n"); return 2; }
+	GdIndex I;
+	gd_index_build(I, rn, rs, O.k, O.w, O.pat, 8, true);
+	// mm_mapopt_update (LR/options.c:64-76)
+	if (O.mid_occ <= 0) {
+		O.mid_occ = gd_index_cal_max_occ(I, mid_occ_frac);
+		if (O.mid_occ < min_mid_occ) O.mid_occ = min_mid_occ;
+		if (max_mid_occ > min_mid_occ && O.mid_occ > max_mid_occ) O.mid_occ = max_mid_occ;
+	}
+	fprintf(stderr, "[map_host_main] keys=%llu mid_occ=%d k=%d w=%d\n", (unsigned long long)I.n_keys, O.mid_occ, O.k, O.w);
+	const GdIdxView V = I.view();
+	const GdRefView R = I.ref();
+	const int g = O.a, bb = O.b < 0 ? O.b : -O.b;
+	int8_t mat[25];
+	for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? (int8_t)g : (int8_t)bb);
+	std::string out;
+	for (size_t ri = 0; ri < qs.size(); ++ri) {
+		const std::string &seq = qs[ri];
+		const int len = (int)seq.size();
+		std::vector<GdReg> regs;
+		if (len > 0) {
+			std::vector<uint8_t> enc(len), rev(len);
+			for (int j = 0; j < len; ++j) enc[j] = gd_nt4((unsigned char)seq[j]);
+			for (int j = 0; j < len; ++j) rev[len - 1 - j] = enc[j] ^ 3; // N (4) becomes 7 exactly as qs_rev does (LR/map.c:1634,:1641)
+			const unsigned maxm = (unsigned)len + 64;
+			std::vector<GdMini> mv(maxm);
+			std::vector<uint32_t> shift_n(O.pat.W);
+			unsigned tot = gd_sketch2(enc.data(), len, O.w, O.k, O.pat, O.max_seeds, mv.data(), maxm, shift_n.data());
+			(void)tot;
+			const int shift = (int)gd_get_shift(V, mv.data(), shift_n.data(), O.pat.W);
+			unsigned n_mv = 0;
+			const uint32_t cap = (O.flag & GD_F_FRAG_MODE) ? (O.max_frag_len == 0 ? 800u : (uint32_t)O.max_frag_len) : UINT32_MAX;
+			const unsigned tel = gd_sketch3(enc.data(), (unsigned)len, O.w, O.k, O.pat, shift, cap, mv.data(), maxm, &n_mv);
+			std::vector<uint64_t> scratch(2 * (size_t)n_mv + 2);
+			if (O.q_occ_frac > 0.0f) n_mv = gd_mz_flt(mv.data(), n_mv, O.mid_occ, O.q_occ_frac, scratch.data());
+			std::vector<GdSeed> seeds(n_mv + 1);
+			int64_t n_a = 0;
+			const int n_m = gd_collect_matches2(V, mv.data(), n_mv, len, O.mid_occ, O.max_max_occ, O.occ_dist, seeds.data(), &n_a);
+			std::vector<GdLoc> af(n_a + 1), ar(n_a + 1), tmp(n_a + 1);
+			unsigned nf = 0, nr = 0;
+			gd_seed_hits(V, seeds.data(), n_m, O.flag, tel, af.data(), ar.data(), &nf, &nr);
+			GdLoc *sf = gd_sort_locs(af.data(), tmp.data(), nf);
+			std::vector<GdLoc> sfv(sf, sf + nf);
+			GdLoc *sr = gd_sort_locs(ar.data(), tmp.data(), nr);
+			std::vector<GdLoc> srv(sr, sr + nr);
+			GdLrVoteOpt VO = {O.vt_dis, O.vt_nb_loc, O.bw, O.vt_cov, O.vt_f, O.vt_df1, O.vt_df2, O.k};
+			GdVt vts[GDM_MAX_VT];
+			const unsigned nc = gd_lr_candidates(sfv.data(), nf, srv.data(), nr, (uint32_t)len, (int32_t)tel, VO, vts);
+			if (nc > 0) {
+				std::vector<GdCand> C(nc);
+				for (unsigned i = 0; i < nc; ++i) C[i].v = vts[i];
+				gd_lr_link_and_boxes(C, O, R, (uint32_t)len);
+				std::vector<GdDpResult> dp(nc);
+				std::vector<gdo_extz_t> ez(nc);
+				std::vector<uint32_t> one(nc);
+				for (unsigned i = 0; i < nc; ++i) {
+					GdCand &c = C[i];
+					memset(&ez[i], 0, sizeof(gdo_extz_t));
+					std::vector<uint8_t> t((size_t)c.tlen + 16, 0);
+					gd_getseq(R, c.target_id, c.target_start, c.target_end + 1, t.data());
+					const uint8_t *q = (c.v.str ? rev.data() : enc.data()) + c.qseq_off;
+					bool exact = false;
+					if (c.exact_score != GD_NEG_INF_SCORE) exact = gdo_exact_match((int)c.qlen, q, (int)c.tlen, t.data()) != 0;
+					if (exact) one[i] = c.qlen << 4, dp[i] = {c.exact_score, &one[i], 1};
+					else {
+						gdo_ksw_extd2((int)c.qlen, q, (int)c.tlen, t.data(), 5, mat, (int8_t)O.q, (int8_t)O.e, (int8_t)O.q2, (int8_t)O.e2, (int)O.bw, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez[i]);
+						dp[i] = {ez[i].score, ez[i].cigar, ez[i].n_cigar};
+					}
+				}
+				gd_lr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs);
+				for (unsigned i = 0; i < nc; ++i) free(ez[i].cigar);
+			}
+		}
+		const char *qual = qq[ri].size() == seq.size() && !qq[ri].empty() ? qq[ri].c_str() : nullptr;
+		if (!regs.empty()) {
+			for (size_t j = 0; j < regs.size(); ++j) {
+				if ((O.flag & GD_F_NO_PRINT_2ND) && regs[j].id != regs[j].parent) continue;
+				out.clear();
+				gd_write_sam(out, R, qn[ri].c_str(), seq.c_str(), qual, len, regs, (int)j, O.flag);
+				puts(out.c_str());
+			}
+		} else {
+			out.clear();
+			gd_write_sam(out, R, qn[ri].c_str(), seq.c_str(), qual, len, regs, -1, O.flag);
+			puts(out.c_str());
+		}
+	}
+	return 0;
+}

@@ -154,6 +154,7 @@ int main(int argc, char **argv)
 			if (it & 1) q.insert(q.begin() + pos, sz, (uint8_t)(g() & 3));
 			else if (pos + sz < (int)q.size()) q.erase(q.begin() + pos, q.begin() + pos + sz);
 		}
+		if (it % 4 == 1) for (auto &c : q) if (c == 4 || (g() % 400) == 0) c = 7; // N of a reverse-complemented read (LR/map.c:1634)
 		const int qlen = (int)q.size();
 		KswConst C;
 		C.q = P[2], C.e = P[3], C.q2 = P[4], C.e2 = P[5];
@@ -167,7 +168,7 @@ int main(int argc, char **argv)
 		for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? P[0] : -P[1]);
 		gdo_extz_t ez;
 		memset(&ez, 0, sizeof(ez));
-		gdo_ksw_extd2(qlen, q.data(), tlen, t.data(), 5, mat, P[2], P[3], P[4], P[5], w, -1, 0, GDO_EZ_APPROX_MAX, &ez);
+		gdo_ksw_extd2(qlen, q.data(), tlen, t.data(), 5, mat, P[2], P[3], P[4], P[5], w, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez);
 		EmuResult e = emulate(LANES, q.data(), qlen, t.data(), tlen, w, C);
 		++n_run;
 		bool ok = e.score == ez.score && (int)e.cigar.size() == ez.n_cigar && (ez.n_cigar == 0 || !memcmp(e.cigar.data(), ez.cigar, 4 * ez.n_cigar));

@@ -1,0 +1,62 @@
+"""CPU: the product's seeding/voting stage code (map_stages.h, compiled for the host) + host geometry and CIGAR
+post-processing (map_host.h), with the oracle's ksw_extd2 standing in for the HIP kernel, reproduce the reference's
+SAM byte for byte: against the committed golden SAM, and -- where oracle/_ref has been built -- against a fresh run of
+the reference binary on a new random read set."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from fixture_io import LR, golden_sam
+
+
+@pytest.fixture(scope="module")
+def host_driver(tmp_path_factory):
+    d = tmp_path_factory.mktemp("maphost")
+    exe = str(d / "map_host")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-w", "-I", os.path.join(ROOT, "genome-on-diet_amd", "csrc"),
+                           "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "emul", "map_host_main.cpp"),
+                           "-x", "c", os.path.join(ROOT, "oracle", "gdo_ksw2.c"), "-o", exe])
+    for f in ("ref.fa", "hifi.fq", "ont.fq"):
+        with gzip.open(os.path.join(LR, f + ".gz"), "rb") as src, open(str(d / f), "wb") as dst:
+            shutil.copyfileobj(src, dst)
+    return exe, str(d)
+
+
+@pytest.mark.parametrize("kind", ["hifi", "ont"])
+def test_host_path_matches_golden_sam(host_driver, kind):
+    exe, d = host_driver
+    cmd = open(os.path.join(LR, kind + ".cmd")).read().split()
+    out = subprocess.run([exe] + cmd + [os.path.join(d, "ref.fa"), os.path.join(d, kind + ".fq")], capture_output=True, text=True, check=True)
+    got = out.stdout.rstrip("\n").split("\n")
+    want = golden_sam(kind)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a == b, (a[:200], b[:200])
+
+
+def test_host_path_matches_reference_binary_on_fresh_reads(host_driver, tmp_path):
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    exe, d = host_driver
+    fq = str(tmp_path / "fresh.fq")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "synth.py"), "reads", fq, "--ref", os.path.join(d, "ref.fa"), "--kind", "hifi", "--n", "20", "--seed", "77"])
+    cmd = open(os.path.join(LR, "hifi.cmd")).read().split()
+    want = subprocess.run([ref_bin, "-t", "4"] + cmd + [os.path.join(d, "ref.fa"), fq], capture_output=True, text=True, check=True).stdout
+    want = [l for l in want.rstrip("\n").split("\n") if not l.startswith("@")]
+    got = subprocess.run([exe] + cmd + [os.path.join(d, "ref.fa"), fq], capture_output=True, text=True, check=True).stdout.rstrip("\n").split("\n")
+
+    def norm(line):
+        # known, documented divergence (DESIGN.md "undefined behaviour in the reference"): for a reverse-strand record
+        # whose window contains reference Ns, mm_update_extra indexes mat[4*5+7] -- two bytes past the 25-entry
+        # matrix on mm_map_frag's stack -- so its ms:i value depends on the reference binary's stack layout.
+        f = line.split("\t")
+        if len(f) > 11 and f[1] in ("16", "272", "2064") and "nn:i:0" not in f:
+            f = [x for x in f if not x.startswith("ms:i:")]
+        return "\t".join(f)
+
+    assert [norm(x) for x in got] == [norm(x) for x in want]
