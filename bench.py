@@ -3,25 +3,32 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[3], the configuration the metric is quoted on): HiFi `map-hifi` reads, ~15 kbp,
-N(15000, 2000) clipped to [5000, 25000], sub 0.2 % / ins 0.1 % / del 0.1 %, band w = 1000, scoring 1,4,6,2,26,1.
-A "step" is one pass of the hot path over one batch of `--batch` reads whose inputs are already resident in HBM.
+Workload = BASELINE.json configs[3], the configuration the metric is quoted on:
+    GDiet-LongReads `-ax map-hifi -Z 10 -W 2 -i 0.2 -k 19 -w 19 -N 1 -r 1000 --vt_dis=650 --vt_nb_loc=5 --vt_df1=0.0106
+    --vt_df2=0.2 -s 400 --vt_cov 0.04 --max_min_gap=4000 --vt_f=0.04 --secondary=yes` (reference README.md:44), synthetic HiFi
+    reads ~15 kbp (N(15000,2000) in [5000,25000], sub .2 % / ins .1 % / del .1 %, 50 % reverse strand) against a synthetic
+    GRCh38-sized reference (24 contigs with the GRCh38 primary-chromosome lengths, i.i.d. ACGT + a 5 % repeat layer at 2 %
+    divergence + N runs).  `--ref-mbp` scales the reference down for quick runs (the JSON says which size ran).
 
-ROUND-1 SCOPE (stated in the JSON line as config.stages): the timed step runs the candidate-alignment stage of
-mm_map_frag -- exact-match pre-filter, banded dual-affine DP (ksw_extd2), backtrack -- i.e. the stage that is
-97.9 % of the reference's per-read time on this configuration; one full-read candidate box per read.
-Sketch / seed lookup / vote are not yet in the timed region; `value` is therefore an upper bound of mapped bases/s
-for the complete path and is labelled as such.
+A "step" = one pass of the whole per-read path (gdiet_hip_map_uploaded: sketch2/shift/sketch3, seed filter + lookup, hit
+sort, vote/vote_2 on the GPU; candidate geometry on host threads; window gather, exact-match, ksw_extd2 DP, backtrack on
+the GPU; mm_update_extra / concatenate_cigars / mm_set_sam_params on host threads) over one batch of reads that is
+already resident in HBM.  value = bases of reads with >= 1 alignment / wall time, summed over ranks (reads are sharded
+over GPUs, index replicated, no collective).
 
-The JSON line carries `roofline` (dominant kernel = ksw_extd2 wave kernel, algorithmic bytes = SURVEY 8d's
-(qlen+tlen-1)*min(w+1,qlen,tlen) + (qlen+tlen) + qlen + ceil(tlen/2) per alignment, divided by the kernel's
-duration measured with HIP events on the launch stream) and `cpu_baseline` (the reference's own
-ksw_extd2_avx512 + ksw_backtrack from oracle/_ref if that has been built, else the oracle port, one core).
+roofline: dominant kernel = ksw_extd2_wave64_kernel; achieved = algorithmic bytes of the launch (per alignment
+(qlen+tlen-1)*min(w+1,qlen,tlen) + (qlen+tlen) + qlen + ceil(tlen/2)) / its duration from HIP events on the launch stream.
+cpu_baseline: the reference binary itself (oracle/_ref/gdiet_lr_avx = GDiet_avx) where it travelled with the repo, mapping
+a bounded sample of the same reads against the contig they were drawn from, all host cores; else the DP stage of the
+oracle port on one core.
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,57 +38,110 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 W_HIFI = 1000
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+          135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+          46709983, 50818468, 156040895, 57227415]
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.zeros(256, np.uint8)
+COMP[[65, 67, 71, 84, 78]] = [84, 71, 67, 65, 78]
 
 
-def synth_hifi_batch(rng, n):
-    """SURVEY 8d 'HiFi reads': target = the reference window a read was drawn from, query = the read."""
-    qs, ts = [], []
-    for _ in range(n):
+def synth_reference(total_mbp, seed=2):
+    """24 contigs in GRCh38 proportions, i.i.d. ACGT, repeat layer ~5 % at 2 % divergence, N runs"""
+    rng = np.random.default_rng(seed)
+    scale = total_mbp * 1e6 / sum(GRCH38)
+    lens = [max(20000, int(l * scale)) for l in GRCH38]
+    contigs = [BASES[rng.integers(0, 4, size=l, dtype=np.uint8)] for l in lens]
+    total = sum(lens)
+    fams = [BASES[rng.integers(0, 4, size=int(rng.integers(300, 6000)), dtype=np.uint8)] for _ in range(2000)]
+    p = np.array(lens, np.float64) / total
+    n_ins = int(0.05 * total / 3150)
+    cs = rng.choice(len(contigs), size=n_ins, p=p)
+    fi = rng.integers(0, len(fams), size=n_ins)
+    for c, f in zip(cs, fi):
+        fam = fams[f]
+        if lens[c] <= len(fam) + 10:
+            continue
+        pos = int(rng.integers(0, lens[c] - len(fam)))
+        cp = fam.copy()
+        m = rng.random(len(cp)) < 0.02
+        cp[m] = BASES[rng.integers(0, 4, size=int(m.sum()))]
+        if rng.random() < 0.5:
+            cp = COMP[cp[::-1]]
+        contigs[c][pos:pos + len(cp)] = cp
+    for _ in range(max(1, int(total * 1e-4 / 50))):
+        c = int(rng.choice(len(contigs), p=p))
+        pos = int(rng.integers(0, lens[c] - 100))
+        contigs[c][pos:pos + int(rng.integers(10, 90))] = 78
+    return ["chr%d" % (i + 1) for i in range(len(contigs))], contigs
+
+
+def synth_hifi_reads(rng, contigs, n, only_contig=None):
+    lens = np.array([len(c) for c in contigs], np.float64)
+    out = []
+    for i in range(n):
         ln = int(np.clip(rng.normal(15000, 2000), 5000, 25000))
-        t = rng.integers(0, 4, size=ln, dtype=np.uint8)
-        q = t.copy()
-        sub = rng.random(ln) < 0.002
-        q[sub] = (q[sub] + rng.integers(1, 4, size=int(sub.sum()))) & 3
-        dele = rng.random(ln) < 0.001
-        q = q[~dele]
-        ins = np.flatnonzero(rng.random(len(q)) < 0.001)
-        q = np.insert(q, ins, rng.integers(0, 4, size=len(ins)).astype(np.uint8))
-        qs.append(np.ascontiguousarray(q, np.uint8)), ts.append(t)
-    return qs, ts
+        c = only_contig if only_contig is not None else int(rng.choice(len(contigs), p=lens / lens.sum()))
+        ln = min(ln, len(contigs[c]) - 2)
+        st = int(rng.integers(0, len(contigs[c]) - ln))
+        s = contigs[c][st:st + ln].copy()
+        m = np.flatnonzero((rng.random(ln) < 0.002) & (s != 78))
+        if len(m):
+            s[m] = BASES[(np.searchsorted(BASES, s[m]) + rng.integers(1, 4, size=len(m))) & 3]
+        s = s[~(rng.random(ln) < 0.001)]
+        ip = np.flatnonzero(rng.random(len(s)) < 0.001)
+        s = np.insert(s, ip, BASES[rng.integers(0, 4, size=len(ip))])
+        if rng.random() < 0.5:
+            s = COMP[s[::-1]]
+        out.append(("r%d_c%d_%d" % (i, c + 1, st), s.tobytes()))
+    return out
 
 
-def algorithmic_bytes(qs, ts, w):
-    tot = 0
-    for q, t in zip(qs, ts):
-        ql, tl = len(q), len(t)
-        tot += (ql + tl - 1) * min(w + 1, ql, tl) + (ql + tl) + ql + (tl + 1) // 2
-    return tot
+def cpu_baseline_reference(names, contigs, rng, cores, budget_s=25.0):
+    """the reference's own GDiet_avx on the host: index the smallest contig with -d, then time mapping only"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")
+    c = int(np.argmin([len(x) for x in contigs]))
+    reads = synth_hifi_reads(rng, contigs, 4 * cores, only_contig=c)
+    hifi = ("-ax map-hifi -Z 10 -W 2 -i 0.2 -k 19 -w 19 -N 1 -r 1000 --vt_dis=650 --vt_nb_loc=5 --vt_df1=0.0106 --vt_df2=0.2 -s 400 "
+            "--vt_cov 0.04 --max_min_gap=4000 --vt_f=0.04 --sort=merge --frag=no -F200,1 --secondary=yes -a").split()
+    with tempfile.TemporaryDirectory() as d:
+        fa, fq, mmi = os.path.join(d, "c.fa"), os.path.join(d, "r.fq"), os.path.join(d, "c.mmi")
+        with open(fa, "wb") as f:
+            f.write(b">" + names[c].encode() + b"\n" + contigs[c].tobytes() + b"\n")
+        with open(fq, "wb") as f:
+            for nm, s in reads:
+                f.write(b"@" + nm.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+        subprocess.run([exe, "-t", str(cores)] + hifi + ["-d", mmi, fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        t0 = time.time()
+        r = subprocess.run([exe, "-t", str(cores)] + hifi + [mmi, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        wall = time.time() - t0
+        err = r.stderr.decode(errors="ignore")
+        m = re.search(r"\[M::main::([0-9.]+)\*[0-9.]+\] loaded/built the index", err)
+        load = float(m.group(1)) if m else 0.0
+        m2 = re.search(r"Real time: ([0-9.]+) sec", err)
+        real = float(m2.group(1)) if m2 else wall
+        names_mapped = {l.split("\t")[0] for l in r.stdout.decode().split("\n") if l and not l.startswith("@") and l.split("\t")[1] != "4"}
+        mapped = sum(len(s) for nm, s in reads if nm in names_mapped)
+        dt = max(1e-6, real - load)
+    return {"value": mapped / dt, "unit": "mapped bases/s", "cores": cores, "kind": "reference",
+            "sample": "%d HiFi reads (%d bases) drawn from the smallest contig (%s, %d bp), GDiet_avx -t %d with a prebuilt .mmi of that "
+                      "contig, mapping wall time only (index load excluded)" % (len(reads), sum(len(s) for _, s in reads), names[c], len(contigs[c]), cores)}
 
 
-def cpu_baseline(qs, ts, w, budget_s=12.0):
-    """the same stage on one host core: reference AVX-512 kernel when oracle/_ref travels with the repo"""
+def cpu_baseline_port(reads_enc, budget_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gdo
     a, b, q, e, q2, e2 = gdo.PRESETS["hifi"]
-    mat = gdo.score_matrix(a, b)
-    if gdo.have_ref("lr_avx"):
-        lib, kind = gdo.load_ref("lr_avx"), "reference"
-        run = lambda qq, tt: gdo.ref_extd2(lib, qq, tt, mat, q, e, q2, e2, w, fn="ksw_extd2_avx512")  # noqa: E731
-    else:
-        lib, kind = gdo.load_oracle(), "port"
-        run = lambda qq, tt: gdo.oracle_extd2(lib, qq, tt, mat, q, e, q2, e2, w)  # noqa: E731
-    t0 = time.time()
-    bases = n = 0
-    for qq, tt in zip(qs, ts):
-        run(qq, tt)
-        bases += len(qq)
+    mat, lib = gdo.score_matrix(a, b), gdo.load_oracle()
+    t0, bases, n = time.time(), 0, 0
+    for s in reads_enc:
+        gdo.oracle_extd2(lib, s, s, mat, q, e, q2, e2, W_HIFI, flag=gdo.EZ_APPROX_MAX | gdo.EZ_AVX512_SC)
+        bases += len(s)
         n += 1
         if time.time() - t0 > budget_s:
             break
-    dt = time.time() - t0
-    return {"value": bases / dt, "unit": "mapped bases/s", "cores": 1, "kind": kind,
-            "sample": "%d HiFi candidate alignments (%d bases) of the same batch, ksw_extd2%s + backtrack, 1 thread"
-                      % (n, bases, "_avx512" if kind == "reference" else " scalar port")}
+    return {"value": bases / (time.time() - t0), "unit": "mapped bases/s", "cores": 1, "kind": "port",
+            "sample": "%d full-read candidate alignments (%d bases): DP + backtrack stage of the oracle port only, 1 thread" % (n, bases)}
 
 
 def main():
@@ -90,6 +150,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="reads per step per GPU")
+    ap.add_argument("--ref-mbp", type=float, default=float(os.environ.get("GDIET_BENCH_REF_MBP", "3088")),
+                    help="size of the synthetic reference in Mbp (default: GRCh38-sized)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,50 +164,40 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cores = max(1, (os.cpu_count() or 8) // max(1, world))
 
     from __graft_entry__ import _load_pkg
     pkg = _load_pkg()
     ctx = pkg.Context(local)
 
+    t_setup = time.time()
+    names, contigs = synth_reference(args.ref_mbp, seed=2)  # the same reference on every rank (replicated index)
+    t_ref = time.time() - t_setup
+    t1 = time.time()
+    mapper = pkg.Mapper(ctx, names, contigs, preset="hifi", n_threads=cores)
+    t_index = time.time() - t1
     rng = np.random.default_rng(5 + rank)  # HiFi reads seed 5 (+rank: read-sharded weak scaling)
-    qs, ts = synth_hifi_batch(rng, args.batch)
-    n = len(qs)
-    qbuf, qoff = pkg.pack(qs)
-    tbuf, toff = pkg.pack(ts)
-    w = np.full(n, W_HIFI, np.int32)
-    caps = np.array([len(a) + len(b) for a, b in zip(qs, ts)], np.int64)
-    coff = np.zeros(n + 1, np.int64)
-    coff[1:] = np.cumsum(caps)
-    d_q = torch.from_numpy(qbuf).to(dev)
-    d_t = torch.from_numpy(tbuf).to(dev)
-    d_coff = torch.from_numpy(coff).to(dev)
-    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_ncig = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_cig = torch.zeros(int(coff[-1]) + 1, dtype=torch.int32, device=dev)
-    score = pkg.KswScore.from_preset("hifi")
-    ctx.reserve(ctx.workspace_bytes(qoff, toff, w))
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step():
-        ctx.ksw_extd2_batch_dev(n, d_q.data_ptr(), d_t.data_ptr(), None, score, d_score.data_ptr(), d_ncig.data_ptr(),
-                                d_cig.data_ptr(), d_coff.data_ptr(), qoff, toff, w, stream)
+    reads = synth_hifi_reads(rng, contigs, args.batch)
+    batch = mapper.upload([s for _, s in reads])
+    read_lens = np.array([len(s) for _, s in reads])
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
+    res = None
     for _ in range(args.warmup):
-        step()
+        res = mapper.map_uploaded(batch)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    dp_ms = []
+    kern, stages = [], []
     for _ in range(args.steps):
-        step()
-        torch.cuda.synchronize(dev)  # results of a batch are consumed by the host before the next one (per-batch latency)
-        dp_ms.append(ctx.last_kernel_ms())
+        res = mapper.map_uploaded(batch)  # returns when every read of the batch has its records on the host
+        kern.append(ctx.last_kernel_ms())
+        stages.append(mapper.stage_seconds())
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -155,15 +207,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    mapped = d_score.cpu().numpy() > -0x40000000
-    bases_step = int(sum(len(q) for q, ok in zip(qs, mapped) if ok))
-    total_bases = bases_step * args.steps * world
+    mapped = np.array([res.n_regs[i] > 0 for i in range(len(reads))])
+    bases_step = int(read_lens[mapped].sum())
+    total = torch.tensor([float(bases_step)], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    total_bases = float(total.item()) * args.steps
+
     if rank == 0:
-        dp = float(np.mean([d for d, _ in dp_ms]))
-        bt = float(np.mean([b for _, b in dp_ms]))
-        alg = algorithmic_bytes(qs, ts, W_HIFI)
+        dp = float(np.mean([d for d, _ in kern]))
+        bt = float(np.mean([b for _, b in kern]))
+        # algorithmic bytes of the DP launch: one candidate box per record; the boxes are ~ the read length on both axes
+        n_align = sum(res.n_regs[i] for i in range(len(reads)))
+        alg = 0
+        for i in range(len(reads)):
+            for j in range(res.n_regs[i]):
+                r = res.regs[i][j]
+                ql, tl = r.qe - r.qs, r.re - r.rs
+                alg += (ql + tl - 1) * min(W_HIFI + 1, ql, tl) + (ql + tl) + ql + (tl + 1) // 2
         achieved = alg / (dp * 1e-3) / 1e9
-        lat = np.array([elapsed / args.steps] * n)  # every read of a batch completes with its batch
+        st = np.mean(np.array(stages), axis=0)
         out = {
             "metric": "mapped bases/sec (whole node), HiFi map-hifi k19w19",
             "value": total_bases / elapsed,
@@ -177,19 +241,31 @@ def main():
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "p50_read_latency_ms": float(np.median(lat) * 1e3),
-            "config": {"workload": "BASELINE configs[3]: HiFi map-hifi k19w19 reads ~15 kbp (N(15000,2000) in [5000,25000], sub .2%/ins .1%/del .1%), band w=1000",
-                       "reads_per_step_per_gpu": n, "bases_per_step_per_gpu": bases_step,
-                       "stages": "candidate alignment only: exact-match + ksw_extd2 DP + backtrack (97.9% of the reference's per-read time); sketch/seed/vote not yet in the timed region",
-                       "parallelism": "reads sharded over %d GPU(s), no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave64_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": dp, "backtrack_kernel_ms": bt,
-                         "gcups": sum((len(q) + len(t) - 1) * min(W_HIFI + 1, len(q), len(t)) for q, t in zip(qs, ts)) / (dp * 1e-3) / 1e9},
+            "p50_read_latency_ms": 1e3 * elapsed / args.steps,
+            "config": {"workload": "BASELINE configs[3]: GDiet-LongReads -ax map-hifi k19 w19 -Z 10 -W 2 -i 0.2 -r 1000 ..., synthetic ~15 kbp HiFi reads vs "
+                                   "synthetic reference of %.0f Mbp in 24 contigs (GRCh38-sized = 3088)" % args.ref_mbp,
+                       "reads_per_step_per_gpu": len(reads), "bases_per_step_per_gpu": int(read_lens.sum()), "mapped_fraction": float(mapped.mean()),
+                       "alignments_per_step": int(n_align), "index_keys": int(mapper.n_keys()), "mid_occ": int(mapper.mid_occ),
+                       "setup_s": {"reference": round(t_ref, 1), "index_build_upload": round(t_index, 1)},
+                       "stage_s_per_step": {"seed_kernel": st[0], "vote_kernel": st[1], "host_geometry": st[2], "gather_dp_backtrack": st[3],
+                                            "host_postprocess": st[4], "other": st[5]},
+                       "p50_read_latency_note": "every read of a batch completes with its batch (batch = ms_per_step)",
+                       "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": cores},
+            "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave64_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": int(alg), "kernel_ms": dp,
+                         "backtrack_kernel_ms": bt},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(qs, ts, W_HIFI)
+            try:
+                if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")):
+                    out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), os.cpu_count() or 8)
+                else:
+                    out["cpu_baseline"] = cpu_baseline_port([np.searchsorted(BASES, np.frombuffer(s, np.uint8)).clip(0, 3).astype(np.uint8) for _, s in reads])
+            except Exception as ex:  # the baseline must never take the benchmark line down
+                out["cpu_baseline"] = {"value": None, "unit": "mapped bases/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out))
+    mapper.free_batch(batch)
+    mapper.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

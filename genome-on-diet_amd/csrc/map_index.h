@@ -57,7 +57,9 @@ static inline int32_t gd_index_cal_max_occ(const GdIndex &I, float f)
 }
 
 // names[i], seqs[i] (ASCII).  final_ge = true reproduces GDiet_avx (the parity target); false the scalar GDiet build.
-static inline void gd_index_build(GdIndex &I, const std::vector<std::string> &names, const std::vector<std::string> &seqs, int k, int w,
+struct GdSeqSpan { const char *p; size_t n; size_t size() const { return n; } bool empty() const { return n == 0; } char operator[](size_t i) const { return p[i]; } };
+
+static inline void gd_index_build(GdIndex &I, const std::vector<std::string> &names, const std::vector<GdSeqSpan> &seqs, int k, int w,
                                   const GdPattern &pat, int n_threads, bool final_ge = true)
 {
 	I.k = k, I.w = w, I.pat = pat;
@@ -72,7 +74,7 @@ static inline void gd_index_build(GdIndex &I, const std::vector<std::string> &na
 		for (;;) {
 			const size_t i = next.fetch_add(1);
 			if (i >= n) break;
-			const std::string &s = seqs[i];
+			const GdSeqSpan &s = seqs[i];
 			std::vector<uint8_t> enc(s.size());
 			for (size_t j = 0; j < s.size(); ++j) enc[j] = gd_nt4((unsigned char)s[j]);
 			// pack into S: whole words are plain stores; the first/last word of a contig may be shared with its neighbours
@@ -141,9 +143,25 @@ static inline void gd_index_build(GdIndex &I, const std::vector<std::string> &na
 	I.tkey.assign(1ull << I.tbits, UINT64_MAX);
 	I.tval.assign(1ull << I.tbits, 0);
 	const uint32_t mask = (uint32_t)((1ull << I.tbits) - 1);
-	for (auto &kv : keys) {
-		uint32_t s = gd_idx_slot(kv.first, I.tbits);
-		while (I.tkey[s] != UINT64_MAX) s = (s + 1) & mask;
-		I.tkey[s] = kv.first, I.tval[s] = kv.second;
-	}
+	// parallel insertion: a slot is claimed with a compare-and-swap on its key, then its value is written by the owner
+	next = 0;
+	const size_t nk = keys.size();
+	auto insw = [&]() {
+		for (;;) {
+			const size_t b0 = next.fetch_add(65536);
+			if (b0 >= nk) break;
+			for (size_t j = b0; j < std::min(nk, b0 + 65536); ++j) {
+				uint32_t s = gd_idx_slot(keys[j].first, I.tbits);
+				for (;;) {
+					uint64_t expect = UINT64_MAX;
+					if (__atomic_compare_exchange_n(&I.tkey[s], &expect, keys[j].first, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+					s = (s + 1) & mask;
+				}
+				I.tval[s] = keys[j].second;
+			}
+		}
+	};
+	th.clear();
+	for (int t = 0; t < std::max(1, n_threads); ++t) th.emplace_back(insw);
+	for (auto &t : th) t.join();
 }

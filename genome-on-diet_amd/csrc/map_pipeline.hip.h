@@ -62,8 +62,9 @@ extern "C" int gdiet_hip_index_build(gdiet_ctx *ctx, gdiet_index **out, int n_se
 	if (!gd_pattern_init(P, pattern, pattern_len)) { ctx->err = "bad pattern"; return GDIET_E_PARAM; }
 	if (w <= 0 || w > GDM_MAX_W || k <= 0 || k > 28) { ctx->err = "k must be in [1,28] and w in [1,64]"; return GDIET_E_PARAM; }
 	gdiet_index *ix = new gdiet_index();
-	std::vector<std::string> nm(n_seq), sq(n_seq);
-	for (int i = 0; i < n_seq; ++i) nm[i] = names && names[i] ? names[i] : "", sq[i].assign(seqs[i], lens[i]);
+	std::vector<std::string> nm(n_seq);
+	std::vector<GdSeqSpan> sq(n_seq);
+	for (int i = 0; i < n_seq; ++i) nm[i] = names && names[i] ? names[i] : "", sq[i].p = seqs[i], sq[i].n = lens[i];
 	gd_index_build(ix->h, nm, sq, k, w, P, n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency(), true);
 	int rc = gd_index_upload(ctx, ix);
 	if (rc) { delete ix; return rc; }

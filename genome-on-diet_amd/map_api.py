@@ -88,15 +88,27 @@ class Mapper:
         p.update(overrides)
         self.p = p
         n = len(seqs)
-        seqs = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+        # sequences: str / bytes (ASCII) or numpy uint8 arrays (ASCII or nt4 codes 0-3; seq_nt4_table maps both)
+        keep = []
+        ptrs = (C.c_void_p * n)()
+        for i, s in enumerate(seqs):
+            if isinstance(s, np.ndarray):
+                s = np.ascontiguousarray(s, np.uint8)
+                keep.append(s)
+                ptrs[i] = s.ctypes.data
+            else:
+                s = s if isinstance(s, bytes) else s.encode()
+                keep.append(s)
+                ptrs[i] = C.cast(C.c_char_p(s), C.c_void_p).value
         names = [s if isinstance(s, bytes) else s.encode() for s in names]
         self.names = [x.decode() for x in names]
         a_names = (C.c_char_p * n)(*names)
-        a_seqs = (C.c_char_p * n)(*seqs)
-        lens = np.array([len(s) for s in seqs], np.uint32)
+        a_seqs = C.cast(ptrs, C.POINTER(C.c_char_p))
+        lens = np.array([len(s) for s in keep], np.uint32)
         self._idx = C.c_void_p()
         rc = self.lib.gdiet_hip_index_build(ctx._h, C.byref(self._idx), n, a_names, a_seqs, lens.ctypes.data_as(C.POINTER(C.c_uint32)),
                                             p["k"], p["w"], p["Z"].encode(), p["W"], n_threads)
+        del keep
         ctx._check(rc)
         # mm_mapopt_update (reference options.c:64-76)
         mid = p.get("mid_occ", 0)

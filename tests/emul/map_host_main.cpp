@@ -122,7 +122,9 @@ int main(int argc, char **argv)
 	std::vector<std::string> rn, rs, qn, qs, qq;
 	if (!read_fastx(pos[0], rn, rs, nullptr) || !read_fastx(pos[1], qn, qs, &qq)) { fprintf(stderr, "cannot read input\n"); return 2; }
 	GdIndex I;
-	gd_index_build(I, rn, rs, O.k, O.w, O.pat, 8, true);
+	std::vector<GdSeqSpan> spans(rs.size());
+	for (size_t i = 0; i < rs.size(); ++i) spans[i].p = rs[i].data(), spans[i].n = rs[i].size();
+	gd_index_build(I, rn, spans, O.k, O.w, O.pat, 8, true);
 	// mm_mapopt_update (LR/options.c:64-76)
 	if (O.mid_occ <= 0) {
 		O.mid_occ = gd_index_cal_max_occ(I, mid_occ_frac);
