@@ -218,14 +218,9 @@ def main():
     if rank == 0:
         dp = float(np.mean([d for d, _ in kern]))
         bt = float(np.mean([b for _, b in kern]))
-        # algorithmic bytes of the DP launch: one candidate box per record; the boxes are ~ the read length on both axes
+        # algorithmic bytes of the DP launch (every candidate box the path aligned), counted by the library from the lengths
         n_align = sum(res.n_regs[i] for i in range(len(reads)))
-        alg = 0
-        for i in range(len(reads)):
-            for j in range(res.n_regs[i]):
-                r = res.regs[i][j]
-                ql, tl = r.qe - r.qs, r.re - r.rs
-                alg += (ql + tl - 1) * min(W_HIFI + 1, ql, tl) + (ql + tl) + ql + (tl + 1) // 2
+        cells, alg = ctx.last_dp_work()
         achieved = alg / (dp * 1e-3) / 1e9
         st = np.mean(np.array(stages), axis=0)
         out = {
@@ -252,7 +247,7 @@ def main():
                        "p50_read_latency_note": "every read of a batch completes with its batch (batch = ms_per_step)",
                        "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": cores},
             "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave64_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": int(alg), "kernel_ms": dp,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": int(alg), "dp_cells_per_launch": int(cells), "gcups": cells / (dp * 1e-3) / 1e9, "kernel_ms": dp,
                          "backtrack_kernel_ms": bt},
         }
         if not args.no_cpu_baseline:

@@ -35,7 +35,9 @@ struct gdiet_ctx {
 	// per-read mapping path (map_pipeline.hip.h)
 	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack;
 	int host_threads = 8;
+	int seed_thread_kernel = 0;
 	double stage_s[6] = {0, 0, 0, 0, 0, 0};
+	uint64_t last_cells = 0, last_alg_bytes = 0; // of the most recent DP launch
 };
 
 #define GD_HIP(call)                                                                              \
@@ -99,6 +101,10 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 			return GDIET_E_HIP;
 		}
 	ctx->host_threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+	{
+		const char *e = getenv("GDIET_SEED_KERNEL");
+		ctx->seed_thread_kernel = e && !strcmp(e, "thread");
+	}
 	*out = ctx;
 	return GDIET_OK;
 }
@@ -243,6 +249,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	ctx->h_tasks.resize(n);
 	const bool wave_scoring_ok = gd_wave_scoring_ok(K);
 	size_t bt = 0;
+	uint64_t cells_sum = 0, alg_sum = 0;
 	std::vector<int32_t> ids[3];
 	int max_cap = 0;
 	ctx->last_mask = 0;
@@ -262,6 +269,13 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 			if (cap * 7 > 160 * 1024 - 1024) { ctx->err = "band wider than the LDS window of the generic kernel"; return GDIET_E_PARAM; }
 			max_cap = std::max(max_cap, cap);
 		}
+		{ // accounting for the roofline: SURVEY.md 8d's per-alignment figure
+			const uint64_t wb = (uint64_t)(T.w < 0 ? std::max(T.qlen, T.tlen) : T.w) + 1;
+			const uint64_t band = std::min<uint64_t>(wb, (uint64_t)std::min(T.qlen, T.tlen));
+			const uint64_t cells = (uint64_t)(T.qlen + T.tlen - 1) * band;
+			cells_sum += cells;
+			alg_sum += cells + (uint64_t)(T.qlen + T.tlen) + (uint64_t)T.qlen + (uint64_t)(T.tlen + 1) / 2;
+		}
 		T.bt_off = (int64_t)bt;
 		bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
 		ids[T.kind].push_back(i);
@@ -279,6 +293,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		id_off[k] = ctx->h_ids.size();
 		ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
 	}
+	ctx->last_cells = cells_sum, ctx->last_alg_bytes = alg_sum;
 	if ((rc = gd_grow(ctx, ctx->arena, bt))) return rc;
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * n))) return rc;
@@ -312,6 +327,14 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	                   d_n_cigar, d_cigar);
 	GD_HIP(hipEventRecord(ctx->ev[2], stream));
 	GD_HIP(hipGetLastError());
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_last_dp_work(const gdiet_ctx *ctx, uint64_t *cells, uint64_t *alg_bytes)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	if (cells) *cells = ctx->last_cells;
+	if (alg_bytes) *alg_bytes = ctx->last_alg_bytes;
 	return GDIET_OK;
 }
 

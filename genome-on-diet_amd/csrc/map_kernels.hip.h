@@ -124,3 +124,118 @@ __global__ __launch_bounds__(64) void map_pack_cigar_kernel(int nb, const uint32
 	const int64_t n = poff[b + 1] - poff[b];
 	for (int64_t i = threadIdx.x; i < n; i += blockDim.x) packed[poff[b] + i] = cig[coff[b] + i];
 }
+
+// ---- wave-parallel form of map_seed_kernel: one 64-lane wavefront per read -------------------------------------------
+// The winnowing automaton is sequential, but exact slices of it can be produced independently (gd_sketch_slice), so the 64
+// lanes sketch 64 slices of the read, compact their minimizers in read order with a wavefront prefix sum, probe the index
+// in parallel, and leave only the short sequential parts (query-occurrence filter, high-occurrence seed selection) to lane 0.
+struct GdEmitLane { // per-lane emission list in scratch
+	GdMini *out;
+	unsigned n, cap;
+	__device__ bool operator()(const GdMini &m)
+	{
+		if (n < cap) out[n] = m;
+		++n;
+		return false;
+	}
+};
+
+// parallel sketch of `dl` sparsified bases; the first min(total, cap) minimizers in read order go to dst[0..).
+// Returns (uniform) the count, or ~0u when a scratch list or dst overflowed.
+__device__ unsigned map_par_sketch(const uint8_t *str, unsigned dl, int w, int k, unsigned shift, const GdPattern &P, GdMini *tmp,
+                                   unsigned R, GdMini *dst, unsigned dst_cap, uint32_t cap)
+{
+	const unsigned lane = threadIdx.x & 63;
+	const unsigned chunk = (dl + 63) / 64;
+	const unsigned i0 = lane * chunk, i1 = i0 + chunk < dl ? i0 + chunk : dl;
+	GdEmitLane e = {tmp + (size_t)lane * R, 0, R};
+	if (chunk && i0 < dl) gd_sketch_slice(str, dl, i0, i1, w, k, 0, shift, P, true, e);
+	unsigned incl = e.n;
+	for (int d = 1; d < 64; d <<= 1) {
+		const unsigned v = __shfl_up(incl, d);
+		if ((int)lane >= d) incl += v;
+	}
+	const unsigned total = __shfl(incl, 63), off = incl - e.n;
+	const unsigned eff = (cap > 0 && total >= cap) ? cap : total;
+	bool bad = e.n > R;
+	for (unsigned j = 0; j < e.n && !bad; ++j) {
+		const unsigned p = off + j;
+		if (p >= eff) break;
+		if (p < dst_cap) dst[p] = e.out[j];
+		else bad = true;
+	}
+	return __any(bad) ? ~0u : eff;
+}
+
+__global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const uint8_t *__restrict__ reads, const int64_t *__restrict__ roff,
+                                                           GdIdxView I, MapDevOpt O, const MapReadScratch *__restrict__ sc, GdMini *__restrict__ mv_arena,
+                                                           uint64_t *__restrict__ u64_arena, GdSeed *__restrict__ seed_arena, MapSeedOut *__restrict__ out)
+{
+	const int rid = blockIdx.x;
+	if (rid >= n_reads) return;
+	const unsigned lane = threadIdx.x;
+	const uint8_t *str = reads + roff[rid];
+	const int len = (int)(roff[rid + 1] - roff[rid]);
+	MapSeedOut o;
+	o.n_seeds = 0, o.shift = 0, o.tel = (uint32_t)len, o.pad = 0, o.n_a = 0;
+	if (len <= 0) { if (lane == 0) out[rid] = o; return; }
+	const MapReadScratch S = sc[rid];
+	GdMini *mv = mv_arena + S.mv_off;
+	GdMini *tmp = (GdMini *)(u64_arena + S.u64_off); // 2*mv_cap uint64 = mv_cap GdMini
+	GdSeed *seeds = seed_arena + S.seed_off;
+	const unsigned R = S.mv_cap / 64;
+	// S1: mm_sketch2 -- every phase, phase 0 on the cropped read, later phases capped at phase 0's count (LR/sketch.c:2174-2223)
+	unsigned len_crop, total = 0;
+	uint32_t cap;
+	if (O.max_seeds < 1) len_crop = (unsigned)((float)O.max_seeds * len), cap = UINT32_MAX;
+	else len_crop = (unsigned)len, cap = (uint32_t)O.max_seeds;
+	uint32_t shift_n[64];
+	bool bad = false;
+	for (int shift = 0; shift < O.pat.W; ++shift) {
+		const unsigned dl = gd_diet_len(O.pat, len_crop, (unsigned)shift);
+		const unsigned n = map_par_sketch(str, dl, O.w, O.k, (unsigned)shift, O.pat, tmp, R, mv + total, S.mv_cap - total, cap == UINT32_MAX ? 0u : cap);
+		__syncthreads();
+		if (n == ~0u) { bad = true; break; }
+		shift_n[shift] = n, total += n;
+		if (cap == UINT32_MAX) len_crop = (unsigned)len, cap = n;
+	}
+	if (bad) { o.n_seeds = -1; if (lane == 0) out[rid] = o; return; }
+	// S3: mm_get_shift -- probes in parallel, one sum per phase
+	{
+		unsigned best = 0, base = 0;
+		for (int i = 0; i < O.pat.W; ++i) {
+			unsigned cur = 0;
+			for (unsigned j = lane; j < shift_n[i]; j += 64) {
+				uint64_t st;
+				cur += gd_idx_get(I, mv[base + j].x >> 8, &st);
+			}
+			for (int d = 32; d > 0; d >>= 1) cur += __shfl_xor(cur, d);
+			if (cur > best) o.shift = i, best = cur;
+			base += shift_n[i];
+		}
+	}
+	__syncthreads();
+	// S2: mm_sketch3 at the chosen phase
+	unsigned n_mv;
+	{
+		const unsigned dl = gd_diet_len(O.pat, (unsigned)len, (unsigned)o.shift);
+		n_mv = map_par_sketch(str, dl, O.w, O.k, (unsigned)o.shift, O.pat, tmp, R, mv, S.mv_cap, O.max_nb_seeds == UINT32_MAX ? 0u : O.max_nb_seeds);
+		__syncthreads();
+		if (n_mv == ~0u) { o.n_seeds = -1; if (lane == 0) out[rid] = o; return; }
+		if (O.max_nb_seeds != UINT32_MAX && O.max_nb_seeds > 0 && n_mv == O.max_nb_seeds) o.tel = (uint32_t)(mv[n_mv - 1].y >> 1); // :2010-2012
+	}
+	// S4: mm_seed_mz_flt (sequential; needs the sorted multiset of hashes)
+	if (O.q_occ_frac > 0.0f && (int64_t)n_mv > (int64_t)O.mid_occ) {
+		unsigned nn = 0;
+		if (lane == 0) nn = gd_mz_flt(mv, n_mv, O.mid_occ, O.q_occ_frac, u64_arena + S.u64_off);
+		__syncthreads();
+		n_mv = __shfl(nn, 0);
+	}
+	// S5: probes in parallel, then the sequential selection
+	for (unsigned j = lane; j < n_mv; j += 64) gd_collect_probe(I, mv[j], seeds[j]);
+	__syncthreads();
+	if (lane == 0) {
+		o.n_seeds = gd_collect_finish(seeds, (int)n_mv, len, O.mid_occ, O.max_max_occ, O.occ_dist, &o.n_a);
+		out[rid] = o;
+	}
+}

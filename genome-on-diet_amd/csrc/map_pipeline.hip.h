@@ -244,8 +244,12 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	const int64_t *d_roff = (const int64_t *)B->d_roff;
 	ctx->stage_s[5] += gd_now() - t0, t0 = gd_now();
 	// ---- S1-S5 ----------------------------------------------------------------------------------------------------
-	hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
-	                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
+	if (ctx->seed_thread_kernel) // one read per thread: the plain sequential form, kept for A/B checks (GDIET_SEED_KERNEL=thread)
+		hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+		                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
+	else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
+		hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+		                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 	std::vector<MapSeedOut> so(n);
 	GD_HIP(hipMemcpyAsync(so.data(), ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
 	GD_HIP(hipStreamSynchronize(s));

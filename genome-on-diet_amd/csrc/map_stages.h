@@ -64,16 +64,22 @@ GDM_HD unsigned gd_diet_len(const GdPattern &P, unsigned len, unsigned shift)
 // `emit(m)` is called for every minimizer the reference pushes, in the same order; it returns true to stop
 // (the two capped variants return from inside the loop).  final_ge: the final flush uses l >= w+k-1 (sketch2/3 and the
 // AVX-512 mm_sketch, :607) instead of l > w+k-1 (scalar mm_sketch, :1760).
+// Chunked execution (used by the wave-parallel kernels, where each lane sketches one slice of the read): the automaton's
+// state after >= k-1+w steps is a pure function of the last w k-mers and of l (the run length of non-N bases, which only
+// matters below w+k), so a slice [i_emit, i_end) can be produced exactly by starting w+k steps earlier with the true l
+// and suppressing every emission before i_emit.  i_begin/l_init describe that warm-up start; do_final = the slice is the
+// last one and performs the end-of-sequence flush.
 template <class Emit>
-GDM_HD void gd_sketch_core(const uint8_t *str, unsigned diet_len, int w, int k, uint32_t rid, unsigned shift,
-                           const GdPattern &P, bool final_ge, Emit &emit)
+GDM_HD void gd_sketch_range(const uint8_t *str, unsigned i_begin, unsigned i_emit, unsigned i_end, int l_init, bool do_final, int w, int k,
+                            uint32_t rid, unsigned shift, const GdPattern &P, bool final_ge, Emit &emit)
 {
 	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
 	uint64_t kmer[2] = {0, 0};
 	GdMini buf[GDM_MAX_W], mn = {UINT64_MAX, UINT64_MAX};
-	int l = 0, buf_pos = 0, min_pos = 0;
+	int l = l_init, buf_pos = 0, min_pos = 0;
 	for (int j = 0; j < w; ++j) buf[j].x = buf[j].y = UINT64_MAX;
-	for (unsigned i = 0; i < diet_len; ++i) {
+#define GDM_EMIT(m_) do { if (i >= i_emit) { if (emit(m_)) return; } } while (0)
+	for (unsigned i = i_begin; i < i_end; ++i) {
 		const unsigned real = (i / P.ones) * P.W + P.ones_loc[i % P.ones] + shift; // get_real_location, :20-23
 		const int c = str[real] < 4 ? str[real] : 4;
 		GdMini info = {UINT64_MAX, UINT64_MAX};
@@ -90,18 +96,15 @@ GDM_HD void gd_sketch_core(const uint8_t *str, unsigned diet_len, int w, int k, 
 				}
 			}
 		} else {
-			if (l >= w + k - 1 && mn.x != UINT64_MAX)
-				if (emit(mn)) return;
+			if (l >= w + k - 1 && mn.x != UINT64_MAX) GDM_EMIT(mn);
 			l = 0;
 		}
 		buf[buf_pos] = info;
 		if (info.x <= mn.x) { // a new minimum (ties: the rightmost wins); write the old one
-			if (l >= w + k && mn.x != UINT64_MAX)
-				if (emit(mn)) return;
+			if (l >= w + k && mn.x != UINT64_MAX) GDM_EMIT(mn);
 			mn = info, min_pos = buf_pos;
 		} else if (buf_pos == min_pos) { // the old minimum left the window
-			if (l >= w + k - 1 && mn.x != UINT64_MAX)
-				if (emit(mn)) return;
+			if (l >= w + k - 1 && mn.x != UINT64_MAX) GDM_EMIT(mn);
 			mn.x = UINT64_MAX;
 			for (int j = buf_pos + 1; j < w; ++j)
 				if (mn.x >= buf[j].x) mn = buf[j], min_pos = j;
@@ -109,24 +112,48 @@ GDM_HD void gd_sketch_core(const uint8_t *str, unsigned diet_len, int w, int k, 
 				if (mn.x >= buf[j].x) mn = buf[j], min_pos = j;
 			if (l >= w + k - 1 && mn.x != UINT64_MAX) { // identical k-mers in the window
 				for (int j = buf_pos + 1; j < w; ++j)
-					if (mn.x == buf[j].x && mn.y != buf[j].y)
-						if (emit(buf[j])) return;
+					if (mn.x == buf[j].x && mn.y != buf[j].y) GDM_EMIT(buf[j]);
 				for (int j = 0; j <= buf_pos; ++j)
-					if (mn.x == buf[j].x && mn.y != buf[j].y)
-						if (emit(buf[j])) return;
+					if (mn.x == buf[j].x && mn.y != buf[j].y) GDM_EMIT(buf[j]);
 			}
 		}
 		if (l == w + k - 1 && mn.x != UINT64_MAX) { // first full window: identical k-mers were not written yet
 			for (int j = buf_pos + 1; j < w; ++j)
-				if (mn.x == buf[j].x && buf[j].y != mn.y)
-					if (emit(buf[j])) return;
+				if (mn.x == buf[j].x && buf[j].y != mn.y) GDM_EMIT(buf[j]);
 			for (int j = 0; j < buf_pos; ++j)
-				if (mn.x == buf[j].x && buf[j].y != mn.y)
-					if (emit(buf[j])) return;
+				if (mn.x == buf[j].x && buf[j].y != mn.y) GDM_EMIT(buf[j]);
 		}
 		if (++buf_pos == w) buf_pos = 0;
 	}
-	if ((final_ge ? l >= w + k - 1 : l > w + k - 1) && mn.x != UINT64_MAX) emit(mn);
+#undef GDM_EMIT
+	if (do_final && (final_ge ? l >= w + k - 1 : l > w + k - 1) && mn.x != UINT64_MAX) emit(mn);
+}
+
+template <class Emit>
+GDM_HD void gd_sketch_core(const uint8_t *str, unsigned diet_len, int w, int k, uint32_t rid, unsigned shift,
+                           const GdPattern &P, bool final_ge, Emit &emit)
+{
+	gd_sketch_range(str, 0, 0, diet_len, 0, true, w, k, rid, shift, P, final_ge, emit);
+}
+
+// slice [i_emit, i_end) of a sketch over diet_len sparsified bases: finds the warm-up start and the run length of non-N
+// bases in front of it, then runs the automaton (see gd_sketch_range)
+template <class Emit>
+GDM_HD void gd_sketch_slice(const uint8_t *str, unsigned diet_len, unsigned i_emit, unsigned i_end, int w, int k, uint32_t rid,
+                            unsigned shift, const GdPattern &P, bool final_ge, Emit &emit)
+{
+	const unsigned wu = (unsigned)(w + k);
+	const unsigned i_begin = i_emit > wu ? i_emit - wu : 0;
+	int l0 = 0;
+	if (i_begin > 0) { // run of non-N bases ending right before i_begin, saturated at w+k+1 (only l < w+k is ever compared)
+		while (l0 < w + k + 1 && (unsigned)l0 < i_begin) {
+			const unsigned i = i_begin - 1 - (unsigned)l0;
+			const unsigned real = (i / P.ones) * P.W + P.ones_loc[i % P.ones] + shift;
+			if (str[real] >= 4) break;
+			++l0;
+		}
+	}
+	gd_sketch_range(str, i_begin, i_emit, i_end, l0, i_end >= diet_len, w, k, rid, shift, P, final_ge, emit);
 }
 
 // ---- flat index view (device mirror of mm_idx_t's buckets; built by map_index.h) -------------------------------
@@ -329,18 +356,14 @@ GDM_HD void gd_seed_select(int32_t n, GdSeed *a, int len, int max_occ, int max_m
 	}
 }
 
-// returns the number of kept seeds; *n_a = total occurrences of the kept seeds
-GDM_HD int gd_collect_matches2(const GdIdxView &I, const GdMini *mv, unsigned n_mv, int qlen, int max_occ, int max_max_occ,
-                               int dist, GdSeed *m, int64_t *n_a)
+// second half of mm_collect_matches2: m[0..n_all) holds one entry per query minimizer in sketch order (n == 0: absent from
+// the index); drop the absent ones, apply mm_seed_select / the max_occ filter, keep the unfiltered.  Returns the number
+// of kept seeds; *n_a = total occurrences of the kept seeds.
+GDM_HD int gd_collect_finish(GdSeed *m, int n_all, int qlen, int max_occ, int max_max_occ, int dist, int64_t *n_a)
 {
 	int n_m0 = 0, n_m = 0;
-	for (unsigned i = 0; i < n_mv; ++i) {
-		uint64_t st;
-		const uint32_t t = gd_idx_get(I, mv[i].x >> 8, &st);
-		if (t == 0) continue;
-		GdSeed &q = m[n_m0++];
-		q.n = t, q.q_pos = (uint32_t)mv[i].y, q.start = (uint32_t)st, q.flt = 0;
-	}
+	for (int i = 0; i < n_all; ++i)
+		if (m[i].n) m[n_m0++] = m[i];
 	if (dist > 0 && max_max_occ > max_occ) gd_seed_select(n_m0, m, qlen, max_occ, max_max_occ, dist);
 	else
 		for (int i = 0; i < n_m0; ++i)
@@ -349,6 +372,20 @@ GDM_HD int gd_collect_matches2(const GdIdxView &I, const GdMini *mv, unsigned n_
 	for (int i = 0; i < n_m0; ++i)
 		if (!m[i].flt) *n_a += m[i].n, m[n_m++] = m[i];
 	return n_m;
+}
+
+// first half: one index probe per query minimizer (mm_seed_collect_all, LR/seed.c:36-62)
+GDM_HD void gd_collect_probe(const GdIdxView &I, const GdMini &mz, GdSeed &q)
+{
+	uint64_t st = 0;
+	q.n = gd_idx_get(I, mz.x >> 8, &st), q.q_pos = (uint32_t)mz.y, q.start = (uint32_t)st, q.flt = 0;
+}
+
+GDM_HD int gd_collect_matches2(const GdIdxView &I, const GdMini *mv, unsigned n_mv, int qlen, int max_occ, int max_max_occ,
+                               int dist, GdSeed *m, int64_t *n_a)
+{
+	for (unsigned i = 0; i < n_mv; ++i) gd_collect_probe(I, mv[i], m[i]);
+	return gd_collect_finish(m, (int)n_mv, qlen, max_occ, max_max_occ, dist, n_a);
 }
 
 // ---- S6: collect_seed_hits (LR/map.c:861-955): occurrences -> loc_t on the forward / reverse strand -------------------

@@ -61,6 +61,7 @@ def load_library():
     lib.gdiet_hip_ksw_workspace_bytes.argtypes = [C.c_int, i64p, i64p, i32p]
     lib.gdiet_hip_ksw_workspace_bytes.restype = C.c_size_t
     lib.gdiet_hip_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.gdiet_hip_last_dp_work.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.gdiet_hip_ksw_extd2_batch.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, i32p, C.POINTER(KswScore),
                                               i32p, i32p, u32p, i64p]
     lib.gdiet_hip_ksw_extd2_batch_dev.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(KswScore),
@@ -121,6 +122,11 @@ class Context:
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()
         self._check(self.lib.gdiet_hip_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def last_dp_work(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.gdiet_hip_last_dp_work(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def reserve(self, nbytes):

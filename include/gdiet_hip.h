@@ -103,6 +103,9 @@ int gdiet_hip_set_kernel_mode(gdiet_ctx *ctx, int mode);
 /* average device time (ms, HIP events on the launch stream) of the DP kernel(s) and of the backtrack kernel of the
  * most recent *_dev / host batch; only valid after the stream has been synchronised. */
 int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *backtrack_ms);
+/* work of the most recent DP launch: DP cells = sum (qlen+tlen-1)*min(w+1,qlen,tlen), and the algorithmic bytes of
+ * SURVEY.md 8d = cells + (qlen+tlen) + qlen + ceil(tlen/2) per alignment (what bench.py's roofline divides by the kernel time) */
+int gdiet_hip_last_dp_work(const gdiet_ctx *ctx, uint64_t *cells, uint64_t *alg_bytes);
 
 /* ---- B1: the per-read mapping path for a whole batch of reads (LongReads variant) -----------------------------
  * Replaces step 1 of worker_pipeline -- kt_for(n_threads, worker_for, ...) -> mm_map_frag() per read
