@@ -35,6 +35,9 @@ struct gdiet_ctx {
 	// per-read mapping path (map_pipeline.hip.h)
 	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack;
 	int host_threads = 8;
+	int lane_threads = 8;              // host threads this lane may use inside gd_map_range
+	int map_lanes = 1;                 // software-pipeline depth of gdiet_hip_map_uploaded
+	std::vector<gdiet_ctx *> children; // the lanes (child contexts on the same device)
 	int seed_thread_kernel = 0;
 	double stage_s[6] = {0, 0, 0, 0, 0, 0};
 	uint64_t last_cells = 0, last_alg_bytes = 0; // of the most recent DP launch
@@ -112,6 +115,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 {
 	if (!ctx) return;
+	for (gdiet_ctx *c : ctx->children) gdiet_hip_destroy(c);
+	ctx->children.clear();
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar,

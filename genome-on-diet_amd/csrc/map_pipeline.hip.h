@@ -202,19 +202,22 @@ static void gd_opt_from_c(const gdiet_mapopt_t *o, const gdiet_index *ix, GdMapO
 	O.max_seeds = o->max_seeds, O.pat = ix->h.pat;
 }
 
-extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, const gdiet_mapopt_t *copt, gdiet_read_batch *B,
-                                      int32_t *n_regs, gdiet_reg_t **regs)
+// a contiguous slice of a resident read batch
+struct GdBatchView {
+	int n;
+	const int64_t *roff;   // n+1 absolute offsets into enc / d_reads
+	const uint8_t *enc;    // host copy (whole batch)
+	const uint8_t *d_reads;
+	const int64_t *d_roff; // device copy of roff (already offset to the slice)
+};
+
+// the whole per-read path for one slice, on ctx's own stream and buffers (ctx is a lane: the parent context or one of its children)
+static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O, const GdBatchView &B, int32_t *n_regs, gdiet_reg_t **regs)
 {
-	if (!ctx || !ix || !copt || !B || !n_regs || !regs) return GDIET_E_PARAM;
 	(void)hipSetDevice(ctx->device);
-	const int n = B->n;
+	const int n = B.n;
 	for (int i = 0; i < 6; ++i) ctx->stage_s[i] = 0;
 	if (n == 0) return GDIET_OK;
-	GdMapOpt O;
-	gd_opt_from_c(copt, ix, O);
-	if (O.flag & GD_F_SR) { ctx->err = "the ShortReads variant of mm_map_frag is not implemented yet (LongReads only)"; return GDIET_E_PARAM; }
-	if (O.vt_nb_loc + 2 > GDM_MAX_VT) { ctx->err = "vt_nb_loc too large"; return GDIET_E_PARAM; }
-	if (O.mid_occ <= 0) { ctx->err = "mid_occ must be set (mm_mapopt_update)"; return GDIET_E_PARAM; }
 	hipStream_t s = ctx->stream;
 	int rc;
 	double t0 = gd_now();
@@ -222,7 +225,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	std::vector<MapReadScratch> sc(n);
 	uint64_t tot = 0;
 	for (int i = 0; i < n; ++i) {
-		const uint32_t len = (uint32_t)(B->roff[i + 1] - B->roff[i]);
+		const uint32_t len = (uint32_t)(B.roff[i + 1] - B.roff[i]);
 		sc[i].mv_cap = len / 3 + 512, sc[i].mv_off = tot, sc[i].u64_off = 2 * tot, sc[i].seed_off = tot, sc[i].pad = 0;
 		tot += sc[i].mv_cap;
 	}
@@ -240,8 +243,8 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	D.flag = O.flag, D.pat = O.pat;
 	D.vote.vt_dis = O.vt_dis, D.vote.vt_nb_loc = O.vt_nb_loc, D.vote.bw = O.bw, D.vote.vt_cov = O.vt_cov, D.vote.vt_f = O.vt_f;
 	D.vote.vt_df1 = O.vt_df1, D.vote.vt_df2 = O.vt_df2, D.vote.k = O.k;
-	const uint8_t *d_reads = (const uint8_t *)B->d_reads;
-	const int64_t *d_roff = (const int64_t *)B->d_roff;
+	const uint8_t *d_reads = (const uint8_t *)B.d_reads;
+	const int64_t *d_roff = (const int64_t *)B.d_roff;
 	ctx->stage_s[5] += gd_now() - t0, t0 = gd_now();
 	// ---- S1-S5 ----------------------------------------------------------------------------------------------------
 	if (ctx->seed_thread_kernel) // one read per thread: the plain sequential form, kept for A/B checks (GDIET_SEED_KERNEL=thread)
@@ -272,12 +275,12 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
 	const GdRefView R = ix->h.ref();
 	std::vector<std::vector<GdCand>> cand(n);
-	gd_parallel_for(ctx->host_threads, n, [&](int i) {
+	gd_parallel_for(ctx->lane_threads, n, [&](int i) {
 		const unsigned nc = vo[i].n_cand;
 		if (!nc) return;
 		cand[i].resize(nc);
 		for (unsigned j = 0; j < nc; ++j) cand[i][j].v = vo[i].cand[j];
-		gd_lr_link_and_boxes(cand[i], O, R, (uint32_t)(B->roff[i + 1] - B->roff[i]));
+		gd_lr_link_and_boxes(cand[i], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
 	});
 	std::vector<int> box_first(n + 1, 0);
 	for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + (int)cand[i].size();
@@ -290,9 +293,9 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		for (size_t j = 0; j < cand[i].size(); ++j) {
 			const GdCand &c = cand[i][j];
 			const int b = box_first[i] + (int)j;
-			const uint32_t rl = (uint32_t)(B->roff[i + 1] - B->roff[i]);
+			const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
 			MapBox &M = boxes[b];
-			M.read_off = B->roff[i], M.read_len = rl, M.qseq_off = c.qseq_off, M.qlen = c.qlen, M.tlen = c.tlen, M.rev = c.v.str;
+			M.read_off = B.roff[i], M.read_len = rl, M.qseq_off = c.qseq_off, M.qlen = c.qlen, M.tlen = c.tlen, M.rev = c.v.str;
 			// a window hanging off a contig (or a wrapped coordinate) reads stale memory in the reference; here the part that
 			// does not exist is zero-filled and absurd sizes are refused
 			uint32_t avail = 0;
@@ -352,12 +355,12 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	}
 	ctx->stage_s[3] += gd_now() - t0, t0 = gd_now();
 	// ---- P1-P3 (host threads) ---------------------------------------------------------------------------------------------
-	gd_parallel_for(ctx->host_threads, n, [&](int i) {
+	gd_parallel_for(ctx->lane_threads, n, [&](int i) {
 		n_regs[i] = 0, regs[i] = nullptr;
 		const size_t nc = cand[i].size();
 		if (!nc) return;
-		const uint32_t rl = (uint32_t)(B->roff[i + 1] - B->roff[i]);
-		const uint8_t *enc = B->enc.data() + B->roff[i];
+		const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
+		const uint8_t *enc = B.enc + B.roff[i];
 		std::vector<uint8_t> rev;
 		bool need_rev = false;
 		for (auto &c : cand[i]) need_rev |= c.v.str != 0;
@@ -372,6 +375,74 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		gd_regs_out(out, &n_regs[i], &regs[i]);
 	});
 	ctx->stage_s[4] += gd_now() - t0;
+	return GDIET_OK;
+}
+
+
+extern "C" int gdiet_hip_set_map_lanes(gdiet_ctx *ctx, int n)
+{
+	if (!ctx || n < 1 || n > 16) return GDIET_E_PARAM;
+	ctx->map_lanes = n;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, const gdiet_mapopt_t *copt, gdiet_read_batch *B,
+                                      int32_t *n_regs, gdiet_reg_t **regs)
+{
+	if (!ctx || !ix || !copt || !B || !n_regs || !regs) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	const int n = B->n;
+	for (int i = 0; i < 6; ++i) ctx->stage_s[i] = 0;
+	if (n == 0) return GDIET_OK;
+	GdMapOpt O;
+	gd_opt_from_c(copt, ix, O);
+	if (O.flag & GD_F_SR) { ctx->err = "the ShortReads variant of mm_map_frag is not implemented yet (LongReads only)"; return GDIET_E_PARAM; }
+	if (O.vt_nb_loc + 2 > GDM_MAX_VT) { ctx->err = "vt_nb_loc too large"; return GDIET_E_PARAM; }
+	if (O.mid_occ <= 0) { ctx->err = "mid_occ must be set (mm_mapopt_update)"; return GDIET_E_PARAM; }
+	const int lanes = std::max(1, std::min(ctx->map_lanes, (n + 255) / 256));
+	if (lanes == 1) {
+		ctx->lane_threads = ctx->host_threads;
+		GdBatchView V = {n, B->roff.data(), B->enc.data(), (const uint8_t *)B->d_reads, (const int64_t *)B->d_roff};
+		return gd_map_range(ctx, ix, O, V, n_regs, regs);
+	}
+	// Software pipeline over slices of the batch: every lane (a child context with its own stream, workspace and host threads)
+	// runs the whole chain for one slice at a time, so the latency-bound kernels (seed, vote, backtrack), the transfers and the
+	// host stages of one slice overlap with the DP kernel of the others.  No result depends on the slicing.
+	while ((int)ctx->children.size() < lanes) {
+		gdiet_ctx *c = nullptr;
+		int rc = gdiet_hip_init(&c, ctx->device);
+		if (rc) { ctx->err = "cannot create a pipeline lane"; return rc; }
+		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel;
+		ctx->children.push_back(c);
+	}
+	const int n_slices = std::min(n, lanes * 2);
+	std::atomic<int> next(0);
+	std::vector<int> rcs(lanes, 0);
+	std::vector<std::thread> th;
+	for (int l = 0; l < lanes; ++l)
+		th.emplace_back([&, l]() {
+			gdiet_ctx *c = ctx->children[l];
+			c->kernel_mode = ctx->kernel_mode;
+			c->lane_threads = std::max(1, ctx->host_threads / lanes);
+			double acc[6] = {0, 0, 0, 0, 0, 0};
+			for (;;) {
+				const int sl = next.fetch_add(1);
+				if (sl >= n_slices || rcs[l]) break;
+				const int lo = (int)((int64_t)n * sl / n_slices), hi = (int)((int64_t)n * (sl + 1) / n_slices);
+				GdBatchView V = {hi - lo, B->roff.data() + lo, B->enc.data(), (const uint8_t *)B->d_reads, (const int64_t *)B->d_roff + lo};
+				rcs[l] = gd_map_range(c, ix, O, V, n_regs + lo, regs + lo);
+				for (int i = 0; i < 6; ++i) acc[i] += c->stage_s[i];
+			}
+			for (int i = 0; i < 6; ++i) c->stage_s[i] = acc[i];
+		});
+	for (auto &t : th) t.join();
+	ctx->last_mask = 0, ctx->last_cells = 0, ctx->last_alg_bytes = 0;
+	for (int l = 0; l < lanes; ++l) {
+		gdiet_ctx *c = ctx->children[l];
+		if (rcs[l]) { ctx->err = c->err; return rcs[l]; }
+		for (int i = 0; i < 6; ++i) ctx->stage_s[i] += c->stage_s[i];
+		ctx->last_mask |= c->last_mask;
+	}
 	return GDIET_OK;
 }
 

@@ -61,6 +61,7 @@ def _bind(lib):
     lib.gdiet_hip_batch_destroy.restype = None
     lib.gdiet_hip_map_stage_seconds.argtypes = [vp, C.POINTER(C.c_double)]
     lib.gdiet_hip_set_host_threads.argtypes = [vp, C.c_int]
+    lib.gdiet_hip_set_map_lanes.argtypes = [vp, C.c_int]
     lib.gdiet_hip_sam_record.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(Reg), C.c_int32, C.c_int32,
                                          C.c_int64, C.c_char_p, C.c_size_t]
     lib.gdiet_hip_sam_record.restype = C.c_size_t
@@ -157,6 +158,10 @@ class Mapper:
         regs = (C.POINTER(Reg) * n)()
         self.ctx._check(self.lib.gdiet_hip_map_uploaded(self.ctx._h, self._idx, C.byref(self.opt), h, n_regs, regs))
         return MapResult(self.lib, n, n_regs, regs)
+
+    def set_lanes(self, n):
+        """software-pipeline depth of map()/map_uploaded() (gdiet_hip_set_map_lanes); results do not depend on it"""
+        self.ctx._check(self.lib.gdiet_hip_set_map_lanes(self.ctx._h, n))
 
     def free_batch(self, batch):
         self.lib.gdiet_hip_batch_destroy(self.ctx._h, batch[0])

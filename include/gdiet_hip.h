@@ -175,6 +175,10 @@ void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *batch);
 /* seconds spent in the stages of the most recent map call: [0] seed kernel, [1] vote kernel, [2] host geometry,
  * [3] gather + DP + backtrack kernels, [4] host post-processing, [5] transfers/other */
 int gdiet_hip_map_stage_seconds(const gdiet_ctx *ctx, double out[6]);
+/* software-pipeline depth of gdiet_hip_map_uploaded / gdiet_hip_map_batch: the batch is cut into slices that run the whole
+ * chain on `n` independent lanes (stream + workspace + host threads each), overlapping the latency-bound stages of one slice
+ * with the DP kernel of the others.  1 (default) = no pipelining.  Results do not depend on it. */
+int gdiet_hip_set_map_lanes(gdiet_ctx *ctx, int n);
 /* number of host threads used for geometry / CIGAR post-processing (default: hardware concurrency) */
 int gdiet_hip_set_host_threads(gdiet_ctx *ctx, int n);
 

@@ -43,6 +43,15 @@ def test_map_uploaded_is_idempotent(gpu_ctx, pkg):
         r2 = m.map_uploaded(b)
         s2 = [m.sam(r2, i, reads[i][0], reads[i][1], reads[i][2]) for i in range(len(reads))]
         assert s1 == s2
+        # ... and slicing the batch over pipeline lanes must not change a byte either
+        b3 = m.upload([r[1] for r in reads] * 12)  # 336 reads -> 2 lanes x 2 slices
+        m.set_lanes(3)
+        r3 = m.map_uploaded(b3)
+        m.set_lanes(1)
+        for rep in range(12):
+            s3 = [m.sam(r3, rep * len(reads) + i, reads[i][0], reads[i][1], reads[i][2]) for i in range(len(reads))]
+            assert s3 == s1
+        m.free_batch(b3)
         m.free_batch(b)
     finally:
         m.close()
