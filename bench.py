@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="reads per step per GPU")
     ap.add_argument("--ref-mbp", type=float, default=float(os.environ.get("GDIET_BENCH_REF_MBP", "3088")),
                     help="size of the synthetic reference in Mbp (default: GRCh38-sized)")
-    ap.add_argument("--lanes", type=int, default=4, help="software-pipeline depth inside a step (gdiet_hip_set_map_lanes)")
+    ap.add_argument("--lanes", type=int, default=1, help="software-pipeline depth inside a step (gdiet_hip_set_map_lanes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

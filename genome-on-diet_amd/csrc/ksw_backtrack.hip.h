@@ -75,29 +75,51 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 			last = (uint32_t)(len_) << 4 | (uint32_t)(op_), have = 1;            \
 		}                                                                        \
 	} while (0)
+	// The walk is a chain of dependent one-byte loads (one HBM round trip per step if done naively).  Alignments stay on a
+	// diagonal most of the time, so the bytes of the next GD_BT_PF cells along the current diagonal are fetched together
+	// (independent loads, one round trip) and consumed for as long as the path really moves diagonally; any indel step
+	// leaves the predicted diagonal and triggers a new fetch from the cell it arrives at.  Pure latency hiding: the visited
+	// cells and the state machine are exactly those of ksw_backtrack.
+#define GD_BT_PF 16
 	while (i >= 0 && j >= 0) {
-		const int r = i + j;
-		int st0, en0;
-		gd_band(r, qlen, tlen, w, st0, en0);
-		const int off = st0 & ~15, off_end = en0 | 15;
-		int force_state = -1;
-		if (i < off) force_state = 2;
-		if (i > off_end) force_state = 1;
-		uint32_t tmp = force_state < 0 ? p[gd_bt_index(T, r, i, off)] : 0;
-		if (force_state < 0 && T.kind != GD_KIND_GENERIC) {
-			// wave kernels store (4-d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6 with n* = "no continuation"; rebuild the
-			// reference's byte d | cX<<3 | cY<<4 | cX2<<5 | cY2<<6 (SR/ksw2.h:127-130)
-			const uint32_t nb = ~tmp;
-			tmp = (4u - (tmp & 7u)) | ((nb >> 3) & 0x08u) | ((nb >> 1) & 0x10u) | ((nb << 1) & 0x20u) | ((nb << 3) & 0x40u);
+		uint8_t pf[GD_BT_PF];
+		int fs[GD_BT_PF];
+		const int i0 = i, j0 = j;
+#pragma unroll
+		for (int k = 0; k < GD_BT_PF; ++k) {
+			const int ik = i0 - k, jk = j0 - k;
+			fs[k] = -1, pf[k] = 0;
+			if (ik >= 0 && jk >= 0) {
+				const int r = ik + jk;
+				int st0, en0;
+				gd_band(r, qlen, tlen, w, st0, en0);
+				const int off = st0 & ~15, off_end = en0 | 15;
+				if (ik < off) fs[k] = 2;
+				if (ik > off_end) fs[k] = 1;
+				if (fs[k] < 0) pf[k] = p[gd_bt_index(T, r, ik, off)];
+			}
 		}
-		if (state == 0) state = tmp & 7;
-		else if (!(tmp >> (state + 2) & 1)) state = 0;
-		if (state == 0) state = tmp & 7;
-		if (force_state >= 0) state = force_state;
-		if (state == 0) { GD_PUSH(0, 1); --i, --j; }
-		else if (state == 1 || state == 3) { GD_PUSH(2, 1); --i; }
-		else { GD_PUSH(1, 1); --j; }
+#pragma unroll
+		for (int k = 0; k < GD_BT_PF; ++k) {
+			if (i != i0 - k || j != j0 - k || i < 0 || j < 0) break; // left the predicted diagonal (or finished)
+			const int force_state = fs[k];
+			uint32_t tmp = pf[k];
+			if (force_state < 0 && T.kind != GD_KIND_GENERIC) {
+				// wave kernels store (4-d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6 with n* = "no continuation"; rebuild the
+				// reference's byte d | cX<<3 | cY<<4 | cX2<<5 | cY2<<6 (SR/ksw2.h:127-130)
+				const uint32_t nb = ~tmp;
+				tmp = (4u - (tmp & 7u)) | ((nb >> 3) & 0x08u) | ((nb >> 1) & 0x10u) | ((nb << 1) & 0x20u) | ((nb << 3) & 0x40u);
+			}
+			if (state == 0) state = tmp & 7;
+			else if (!(tmp >> (state + 2) & 1)) state = 0;
+			if (state == 0) state = tmp & 7;
+			if (force_state >= 0) state = force_state;
+			if (state == 0) { GD_PUSH(0, 1); --i, --j; }
+			else if (state == 1 || state == 3) { GD_PUSH(2, 1); --i; }
+			else { GD_PUSH(1, 1); --j; }
+		}
 	}
+#undef GD_BT_PF
 	if (i >= 0) GD_PUSH(2, i + 1);
 	if (j >= 0) GD_PUSH(1, j + 1);
 	if (have) { if (nc < cap) cg[nc] = last; ++nc; }

@@ -17,6 +17,18 @@ __device__ __forceinline__ u32 gdw_ror1_wave(u32 v)
 	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false);
 }
 
+// the one fresh query byte per anti-diagonal, read through the scalar cache: an aligned dword at a wave-uniform address
+// (s_load_dword), so that the row loop issues no vector-memory load at all and never has to wait on its own backtrace stores
+__device__ __forceinline__ u32 gdw_seam_byte(const uint8_t *query, int qlen, int j)
+{
+	if (j < 0 || j >= qlen) return 0u;
+	const uintptr_t a = (uintptr_t)(query + j);
+	// constant address space + wave-uniform address => s_load_dword; the aligned dword holding a valid byte stays inside its allocation
+	typedef const __attribute__((address_space(4))) u32 *gdw_const_u32p;
+	const u32 wd = *(gdw_const_u32p)(a & ~(uintptr_t)3);
+	return (wd >> (8 * (a & 3))) & 0xffu;
+}
+
 static inline bool gd_wave_scoring_ok(const KswConst &C)
 {
 	WaveK K;
@@ -56,7 +68,6 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave64_kernel(const KswTask *__
 	WaveLane L;
 	gdw_load_block(L, K, lane, 0, query, qlen, target, tlen);
 	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
-	u32 qnext = 0;
 	for (int r = 0; r <= rend; ++r) {
 		WaveRow W;
 		W.r = r;
@@ -69,11 +80,10 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave64_kernel(const KswTask *__
 		W.set_tr = (W.en0 | 15) >= r;
 		W.ukey = gdw_edge_key(K, r);
 		// (1) row r-1 values of the previous lane, fetched before any lane is touched
-		const u32 pX = gdw_ror1_wave(L.X[7]), pV = gdw_ror1_wave(L.V[7]), pX2 = gdw_ror1_wave(L.X2[7]);
+		const u32 pX = gdw_ror1_wave(L.X[7]), pV = gdw_ror1_wave(L.V[7]), pX2 = gdw_ror1_wave(L.X2[7]), pQ = gdw_ror1_wave(L.Qc[3]);
 		// (2) query window advance; the lane whose block fell below the window takes over block +64
-		if (r > 0) gdw_shift_query(L, qnext);
+		if (r > 0) gdw_shift_query(L, pQ, L.blk == prev_st_, gdw_seam_byte(query, qlen, r - (prev_st_ << 4)));
 		if (advanced && L.blk < W.st_) gdw_load_block(L, K, L.blk + LANES, r, query, qlen, target, tlen);
-		qnext = gdw_qbyte(query, qlen, r + 1 - (L.blk << 4)); // prefetch for the next anti-diagonal
 		// (3) scalar fix-ups and the score row
 		if (W.set_tr) gdw_reset_tr(L, K, W);
 		if (W.st0 != prev_st0 || W.up != prev_up || advanced) gdw_make_sel(L, W.st0, W.up);

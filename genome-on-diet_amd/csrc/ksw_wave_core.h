@@ -191,13 +191,17 @@ GDW_HD void gdw_make_sel(WaveLane &L, int st0, int up)
 	}
 }
 
-// advance the query window by one anti-diagonal: cell i now faces what cell i-1 faced; cell 0 gets `inc`
-GDW_HD void gdw_shift_query(WaveLane &L, u32 inc)
+// advance the query window by one anti-diagonal: cell i now faces what cell i-1 faced.  Cell 0 takes the byte that cell 15
+// of the block below faced on the previous anti-diagonal, i.e. the top byte of the previous lane's Qc[3] (`below`, fetched
+// with the same DPP rotate as the DP state) -- the query streams through the lanes and no lane touches memory.  Only the
+// lane holding the lowest block has nobody below it: it takes `seam`, the one fresh byte query[r - 16*lowest_block].
+GDW_HD void gdw_shift_query(WaveLane &L, u32 below, bool is_lowest, u32 seam)
 {
+	const u32 in = is_lowest ? (seam << 24) : below;
 	L.Qc[3] = gdw_alignbyte(L.Qc[3], L.Qc[2], 3);
 	L.Qc[2] = gdw_alignbyte(L.Qc[2], L.Qc[1], 3);
 	L.Qc[1] = gdw_alignbyte(L.Qc[1], L.Qc[0], 3);
-	L.Qc[0] = (L.Qc[0] << 8) | (inc & 0xffu);
+	L.Qc[0] = gdw_alignbyte(L.Qc[0], in, 3);
 }
 
 // rewrite the persistent score bytes of this lane (every lane, active or not: the rewritten range may spill into

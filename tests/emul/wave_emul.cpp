@@ -41,15 +41,15 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 		W.set_tr = (W.en0 | 15) >= r;
 		W.ukey = gdw_edge_key(K, r);
 		// (1) cross-lane exchange of row r-1 values (DPP wave_ror:1 on the GPU), before anything is modified
-		std::vector<u32> pX(LANES), pV(LANES), pX2(LANES);
+		std::vector<u32> pX(LANES), pV(LANES), pX2(LANES), pQ(LANES);
 		for (int l = 0; l < LANES; ++l) {
 			const int p = (l + LANES - 1) % LANES;
-			pX[l] = L[p].X[7], pV[l] = L[p].V[7], pX2[l] = L[p].X2[7];
+			pX[l] = L[p].X[7], pV[l] = L[p].V[7], pX2[l] = L[p].X2[7], pQ[l] = L[p].Qc[3];
 		}
 		// (2) query window advance / block retirement
 		int reloaded = 0;
 		for (int l = 0; l < LANES; ++l) {
-			if (r > 0) gdw_shift_query(L[l], gdw_qbyte(query, qlen, r - (L[l].blk << 4)));
+			if (r > 0) gdw_shift_query(L[l], pQ[l], L[l].blk == prev_st_, gdw_qbyte(query, qlen, r - (prev_st_ << 4)));
 			if (L[l].blk < W.st_) gdw_load_block(L[l], K, L[l].blk + LANES, r, query, qlen, target, tlen), reloaded = 1;
 		}
 		// (3) per-row scalar fix-ups and the score row

@@ -72,13 +72,13 @@ int main()
 		{"v_bitop3_b32", k_bitop3}, {"v_max3_i32", k_max3}, {"v_pk_mad_u16", k_pkmad}, {"v_pk_lshrrev_b16", k_pklshr}, {"v_add3_u32", k_add3}, {"v_bfe_i32", k_bfe}};
 	const int iters = 4000, per_iter = 16;
 	unsigned *d_out; long long *d_cyc;
-	CHK(hipMalloc(&d_out, 256 * 4 * 8 * 256 * 4));
+	CHK(hipMalloc(&d_out, 256 * 4 * 8 * 256 * 4 * 2));
 	CHK(hipMalloc(&d_cyc, 256 * 4 * 8 * 8 * 8));
 	hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-	printf("%-28s %10s %10s %10s   (cycles per wave-instruction seen by ONE wave; x waves/SIMD = SIMD cost)\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD");
+	printf("%-28s %10s %10s %10s %10s %10s %10s  (cycles per wave-instruction seen by ONE wave; x waves/SIMD = SIMD cost)\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "5", "6", "8");
 	for (auto &k : K) {
 		printf("%-28s", k.name);
-		for (int wps : {1, 2, 4}) {
+		for (int wps : {1, 2, 4, 5, 6, 8}) {
 			const int blocks = 256 * wps; // 256 threads = 4 waves = one per SIMD of a CU
 			hipLaunchKernelGGL(k.f, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 10, 1u);
 			CHK(hipDeviceSynchronize());
@@ -90,7 +90,7 @@ int main()
 			CHK(hipMemcpy(c.data(), d_cyc, sizeof(long long) * blocks * 4, hipMemcpyDeviceToHost));
 			double s = 0; for (auto v : c) s += v;
 			float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-			printf(" %10.2f", s / c.size() / ((double)iters * per_iter));
+			printf(" %5.2f/%4.2fns", s / c.size() / ((double)iters * per_iter) / wps, ms * 1e6 / ((double)iters * per_iter * wps));
 		}
 		printf("\n");
 	}
