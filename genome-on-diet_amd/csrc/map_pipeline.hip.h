@@ -109,6 +109,34 @@ extern "C" int gdiet_hip_index_import(gdiet_ctx *ctx, gdiet_index **out, int k, 
 	return GDIET_OK;
 }
 
+// flat view of the index, the inverse of gdiet_hip_index_import (keys in table order; each position list ascending)
+extern "C" int gdiet_hip_index_export(const gdiet_index *ix, uint64_t *n_keys, uint64_t *n_pos, uint64_t *n_S_words, uint64_t *keys,
+                                      uint32_t *cnt, uint64_t *pos, uint32_t *S, uint64_t *offsets)
+{
+	if (!ix) return GDIET_E_PARAM;
+	const GdIndex &h = ix->h;
+	if (n_keys) *n_keys = h.n_keys;
+	if (n_pos) *n_pos = h.pos.size();
+	if (n_S_words) *n_S_words = h.S.size();
+	if (keys && cnt) {
+		uint64_t j = 0;
+		for (size_t s = 0; s < h.tkey.size(); ++s)
+			if (h.tkey[s] != UINT64_MAX) keys[j] = h.tkey[s], cnt[j] = (uint32_t)h.tval[s], ++j;
+		if (j != h.n_keys) return GDIET_E_PARAM;
+	}
+	if (pos && keys && cnt) { // lists concatenated in the order of keys[]
+		uint64_t o = 0;
+		for (size_t s = 0; s < h.tkey.size(); ++s)
+			if (h.tkey[s] != UINT64_MAX) {
+				const uint64_t st = h.tval[s] >> 32, n = (uint32_t)h.tval[s];
+				for (uint64_t t = 0; t < n; ++t) pos[o++] = h.pos[st + t];
+			}
+	}
+	if (S) memcpy(S, h.S.data(), 4 * h.S.size());
+	if (offsets) for (size_t i = 0; i < h.seq.size(); ++i) offsets[i] = h.seq[i].offset;
+	return GDIET_OK;
+}
+
 extern "C" void gdiet_hip_index_destroy(gdiet_ctx *ctx, gdiet_index *ix)
 {
 	if (!ix) return;

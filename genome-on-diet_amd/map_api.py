@@ -46,6 +46,10 @@ def _bind(lib):
     cpp = C.POINTER(C.c_char_p)
     i32p, u32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
     lib.gdiet_hip_index_build.argtypes = [vp, C.POINTER(vp), C.c_int, cpp, cpp, u32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    u64p = C.POINTER(C.c_uint64)
+    lib.gdiet_hip_index_import.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, cpp, u32p, u64p, u32p,
+                                           C.c_uint64, u64p, u32p, u64p]
+    lib.gdiet_hip_index_export.argtypes = [vp, u64p, u64p, u64p, u64p, u32p, u64p, u32p, u64p]
     lib.gdiet_hip_index_destroy.argtypes = [vp, vp]
     lib.gdiet_hip_index_destroy.restype = None
     lib.gdiet_hip_index_cal_max_occ.argtypes = [vp, C.c_float]
@@ -111,6 +115,46 @@ class Mapper:
                                             p["k"], p["w"], p["Z"].encode(), p["W"], n_threads)
         del keep
         ctx._check(rc)
+        self.lens = lens
+        self._setup_opt()
+
+    @classmethod
+    def from_flat(cls, ctx, names, lens, flat, preset="hifi", **overrides):
+        """the gdiet_hip_index_import route: `flat` = dict(keys, cnt, pos, S, offsets) as a reference-side stub would
+        produce by walking mm_idx_t::B[] (INTEGRATION.md), or as export_index() returns"""
+        self = cls.__new__(cls)
+        self.ctx, self.lib = ctx, load_library()
+        _bind(self.lib)
+        p = dict(PRESETS[preset])
+        p.update(overrides)
+        self.p = p
+        n = len(names)
+        bn = [s if isinstance(s, bytes) else s.encode() for s in names]
+        self.names = [x.decode() for x in bn]
+        self.lens = np.ascontiguousarray(lens, np.uint32)
+        u64, u32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        keys, cnt, pos = (np.ascontiguousarray(flat[k], t) for k, t in (("keys", np.uint64), ("cnt", np.uint32), ("pos", np.uint64)))
+        S, offs = np.ascontiguousarray(flat["S"], np.uint32), np.ascontiguousarray(flat["offsets"], np.uint64)
+        self._idx = C.c_void_p()
+        rc = self.lib.gdiet_hip_index_import(ctx._h, C.byref(self._idx), p["k"], p["w"], p["Z"].encode(), p["W"], n, (C.c_char_p * n)(*bn),
+                                             self.lens.ctypes.data_as(u32), offs.ctypes.data_as(u64), S.ctypes.data_as(u32), len(keys),
+                                             keys.ctypes.data_as(u64), cnt.ctypes.data_as(u32), pos.ctypes.data_as(u64))
+        ctx._check(rc)
+        self._setup_opt()
+        return self
+
+    def export_index(self):
+        u64, u32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        nk, npos, ns = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.lib.gdiet_hip_index_export(self._idx, C.byref(nk), C.byref(npos), C.byref(ns), None, None, None, None, None))
+        keys, cnt, pos = np.zeros(nk.value, np.uint64), np.zeros(nk.value, np.uint32), np.zeros(npos.value, np.uint64)
+        S, offs = np.zeros(ns.value, np.uint32), np.zeros(len(self.names), np.uint64)
+        self.ctx._check(self.lib.gdiet_hip_index_export(self._idx, None, None, None, keys.ctypes.data_as(u64), cnt.ctypes.data_as(u32),
+                                                        pos.ctypes.data_as(u64), S.ctypes.data_as(u32), offs.ctypes.data_as(u64)))
+        return dict(keys=keys, cnt=cnt, pos=pos, S=S, offsets=offs)
+
+    def _setup_opt(self):
+        p = self.p
         # mm_mapopt_update (reference options.c:64-76)
         mid = p.get("mid_occ", 0)
         if mid <= 0:
@@ -162,6 +206,9 @@ class Mapper:
     def set_lanes(self, n):
         """software-pipeline depth of map()/map_uploaded() (gdiet_hip_set_map_lanes); results do not depend on it"""
         self.ctx._check(self.lib.gdiet_hip_set_map_lanes(self.ctx._h, n))
+
+    def set_host_threads(self, n):
+        self.ctx._check(self.lib.gdiet_hip_set_host_threads(self.ctx._h, n))
 
     def free_batch(self, batch):
         self.lib.gdiet_hip_batch_destroy(self.ctx._h, batch[0])

@@ -1,0 +1,52 @@
+"""Multi-GPU form of the path: reads are independent, so ranks own disjoint read ranges, the index is
+replicated, and there is no data-path collective.  The only cross-rank traffic is the bookkeeping below (a barrier
+around the timed region, MAX of the elapsed time, SUM of the mapped bases); on GPUs it goes over RCCL ("nccl"),
+in the CPU tests over gloo."""
+import time
+
+
+def read_range(n_reads, rank, world):
+    """contiguous share of a mini-batch for `rank`: sizes differ by at most one read, order of reads preserved
+    (what a multi-process host would hand each GPU from one kt_for batch, reference map.c:2132)"""
+    base, rem = divmod(n_reads, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def rank_seed(base_seed, rank):
+    """weak scaling: every rank draws its own reads (same distribution, different stream)"""
+    return base_seed + rank
+
+
+class JobClock:
+    """barrier-bracketed wall clock + whole-job aggregation; `dist` is torch.distributed or None (single process)"""
+
+    def __init__(self, dist=None, device=None, sync=None):
+        self.dist, self.device, self.sync = dist, device, sync or (lambda: None)
+        self.t0 = None
+
+    def _barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def start(self):
+        self.sync()
+        self._barrier()
+        self.sync()
+        self.t0 = time.perf_counter()
+
+    def stop(self):
+        self.sync()
+        self._barrier()
+        return time.perf_counter() - self.t0
+
+    def aggregate(self, elapsed, units):
+        """(max over ranks of elapsed, sum over ranks of units)"""
+        if self.dist is None:
+            return float(elapsed), float(units)
+        import torch
+        t = torch.tensor([float(elapsed)], dtype=torch.float64, device=self.device)
+        u = torch.tensor([float(units)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(u, op=self.dist.ReduceOp.SUM)
+        return float(t.item()), float(u.item())

@@ -131,6 +131,11 @@ int gdiet_hip_index_import(gdiet_ctx *ctx, gdiet_index **idx, int k, int w, cons
                            int n_seq, const char *const *names, const uint32_t *lens, const uint64_t *offsets,
                            const uint32_t *S, uint64_t n_keys, const uint64_t *keys, const uint32_t *cnt,
                            const uint64_t *pos);
+/* the inverse of gdiet_hip_index_import: sizes first (array arguments NULL), then the arrays (caller-allocated: n_keys keys and
+ * counts, n_pos positions, n_S_words words of S, n_seq offsets).  What a maintainer needs to write the index back into an
+ * mm_idx_t / .mmi (LR/index.c:428-470 mm_idx_dump) or to check it against mm_idx_get. */
+int gdiet_hip_index_export(const gdiet_index *idx, uint64_t *n_keys, uint64_t *n_pos, uint64_t *n_S_words, uint64_t *keys,
+                           uint32_t *cnt, uint64_t *pos, uint32_t *S, uint64_t *offsets);
 void gdiet_hip_index_destroy(gdiet_ctx *ctx, gdiet_index *idx);
 /* mm_idx_cal_max_occ (LR/index.c:190-210) */
 int32_t gdiet_hip_index_cal_max_occ(const gdiet_index *idx, float frac);

@@ -55,3 +55,32 @@ def test_map_uploaded_is_idempotent(gpu_ctx, pkg):
         m.free_batch(b)
     finally:
         m.close()
+
+
+def test_index_import_route_gives_identical_sam(gpu_ctx, pkg):
+    """gdiet_hip_index_import (what the reference-side stub of INTEGRATION.md feeds from mm_idx_t::B[]) against
+    gdiet_hip_index_build: export -> shuffle the key order (a khash walk has no particular order) -> import -> same SAM"""
+    import numpy as np
+    names, seqs = read_fasta(os.path.join(LR, "ref.fa.gz"))
+    reads = read_fastq(os.path.join(LR, "hifi.fq.gz"))
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset="hifi")
+    try:
+        flat = m.export_index()
+        assert len(flat["keys"]) == m.n_keys() and int(flat["cnt"].sum()) == len(flat["pos"])
+        start = np.concatenate([[0], np.cumsum(flat["cnt"].astype(np.int64))])
+        perm = np.random.default_rng(5).permutation(len(flat["keys"]))
+        pos = np.concatenate([flat["pos"][start[j]:start[j + 1]] for j in perm])
+        for j in perm[:200]:  # every list ascending, as mm_idx_get returns it (LR/index.c:255)
+            lst = flat["pos"][start[j]:start[j + 1]]
+            assert (np.diff(lst.astype(np.int64)) > 0).all()
+        flat2 = dict(keys=flat["keys"][perm], cnt=flat["cnt"][perm], pos=pos, S=flat["S"], offsets=flat["offsets"])
+        m2 = pkg.Mapper.from_flat(gpu_ctx, names, [len(s) for s in seqs], flat2, preset="hifi")
+        try:
+            assert m2.mid_occ == m.mid_occ
+            ra, rb = m.map([r[1] for r in reads]), m2.map([r[1] for r in reads])
+            for i, (qn, sq, ql) in enumerate(reads):
+                assert m.sam(ra, i, qn, sq, ql) == m2.sam(rb, i, qn, sq, ql)
+        finally:
+            m2.close()
+    finally:
+        m.close()

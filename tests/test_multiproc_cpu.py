@@ -1,0 +1,68 @@
+"""N > 1 control path of bench.py on CPU: two processes over gloo exercise exactly the helpers the GPU bench uses
+(read sharding without overlap, barrier-bracketed clock, MAX of time and SUM of mapped bases).  The data path itself has
+no collective, so there is nothing else to rehearse across ranks."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_pkg
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    pkg = load_pkg()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clock = pkg.JobClock(dist, torch.device("cpu"))
+        lo, hi = pkg.read_range(1001, rank, world)
+        clock.start()
+        units = sum(range(lo, hi))  # stands for "bases of the reads this rank mapped"
+        elapsed = clock.stop()
+        fake = 1.0 + rank  # rank 1 is the slow one
+        tmax, total = clock.aggregate(fake, units)
+        q.put((rank, lo, hi, elapsed, tmax, total, pkg.rank_seed(5, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_shard_and_aggregate():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, _, tmax0, tot0, s0), (r1, lo1, hi1, _, tmax1, tot1, s1) = out
+    assert (lo0, hi1) == (0, 1001) and hi0 == lo1 and abs((hi0 - lo0) - (hi1 - lo1)) <= 1
+    assert tmax0 == tmax1 == 2.0  # MAX over ranks
+    assert tot0 == tot1 == float(sum(range(1001)))  # SUM over ranks, nothing lost or double-counted
+    assert s0 != s1
+
+
+@pytest.mark.parametrize("n,world", [(0, 1), (1, 4), (7, 8), (4096, 8), (4097, 3)])
+def test_read_range_partitions_every_read_once(n, world):
+    pkg = load_pkg()
+    cover = []
+    for r in range(world):
+        lo, hi = pkg.read_range(n, r, world)
+        assert 0 <= lo <= hi <= n
+        cover += list(range(lo, hi))
+    assert cover == list(range(n))
