@@ -16,7 +16,7 @@ the GPU; mm_update_extra / concatenate_cigars / mm_set_sam_params on host thread
 already resident in HBM.  value = bases of reads with >= 1 alignment / wall time, summed over ranks (reads are sharded
 over GPUs, index replicated, no collective).
 
-roofline: dominant kernel = ksw_extd2_wave64_kernel; achieved = algorithmic bytes of the launch (per alignment
+roofline: dominant kernel = ksw_extd2_wave_kernel<64>; achieved = algorithmic bytes of the launch (per alignment
 (qlen+tlen-1)*min(w+1,qlen,tlen) + (qlen+tlen) + qlen + ceil(tlen/2)) / its duration from HIP events on the launch stream.
 cpu_baseline: the reference binary itself (oracle/_ref/gdiet_lr_avx = GDiet_avx) where it travelled with the repo, mapping
 a bounded sample of the same reads against the contig they were drawn from, all host cores; else the DP stage of the
@@ -255,7 +255,7 @@ def main():
                                             "host_postprocess": st[4], "other": st[5]},
                        "p50_read_latency_note": "every read of a batch completes with its batch (batch = ms_per_step)",
                        "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": cores, "pipeline_lanes": args.lanes},
-            "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave64_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave_kernel<64>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(alg), "dp_cells_per_launch": int(cells), "gcups": cells / (dp * 1e-3) / 1e9, "kernel_ms": dp,
                          "backtrack_kernel_ms": bt},
         }

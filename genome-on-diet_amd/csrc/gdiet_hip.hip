@@ -284,27 +284,48 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		T.bt_off = (int64_t)bt;
 		bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
 		ids[T.kind].push_back(i);
-		ctx->last_mask |= T.kind == GD_KIND_GENERIC ? 2 : 1;
+		ctx->last_mask |= T.kind == GD_KIND_GENERIC ? 2 : T.kind == GD_KIND_WAVE16 ? 4 : 1;
 	}
 	// longest alignments first inside each class: the tail of the grid is then made of short jobs
 	for (int k = 0; k < 3; ++k)
 		std::stable_sort(ids[k].begin(), ids[k].end(), [&](int a, int b) {
 			const KswTask &A = ctx->h_tasks[a], &B = ctx->h_tasks[b];
-			return (int64_t)A.qlen + A.tlen > (int64_t)B.qlen + B.tlen;
+			if ((int64_t)A.qlen + A.tlen != (int64_t)B.qlen + B.tlen) return (int64_t)A.qlen + A.tlen > (int64_t)B.qlen + B.tlen;
+			if (A.qlen != B.qlen) return A.qlen > B.qlen; // equal geometries become neighbours (16-lane quartets below)
+			return A.w > B.w;
 		});
+	// the 16-lane kernel runs four alignments of identical (qlen, tlen, w) per wavefront: cut the sorted list into quartets
+	// (-1 pads an incomplete one)
+	std::vector<int32_t> quartets;
+	{
+		const std::vector<int32_t> &v = ids[GD_KIND_WAVE16];
+		size_t i = 0;
+		while (i < v.size()) {
+			const KswTask &A = ctx->h_tasks[v[i]];
+			size_t j = i + 1;
+			while (j < v.size() && j < i + 4) {
+				const KswTask &B = ctx->h_tasks[v[j]];
+				if (B.qlen != A.qlen || B.tlen != A.tlen || B.w != A.w) break;
+				++j;
+			}
+			for (size_t k = i; k < i + 4; ++k) quartets.push_back(k < j ? v[k] : -1);
+			i = j;
+		}
+	}
 	ctx->h_ids.clear();
 	size_t id_off[3];
 	for (int k = 0; k < 3; ++k) {
 		id_off[k] = ctx->h_ids.size();
-		ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
+		if (k == GD_KIND_WAVE16) ctx->h_ids.insert(ctx->h_ids.end(), quartets.begin(), quartets.end());
+		else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
 	}
 	ctx->last_cells = cells_sum, ctx->last_alg_bytes = alg_sum;
 	if ((rc = gd_grow(ctx, ctx->arena, bt))) return rc;
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
-	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * ctx->h_ids.size()))) return rc;
 	if ((rc = gd_grow(ctx, ctx->status, sizeof(int32_t) * n))) return rc;
 	GD_HIP(hipMemcpyAsync(ctx->tasks.p, ctx->h_tasks.data(), sizeof(KswTask) * n, hipMemcpyHostToDevice, stream));
-	GD_HIP(hipMemcpyAsync(ctx->ids.p, ctx->h_ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
+	GD_HIP(hipMemcpyAsync(ctx->ids.p, ctx->h_ids.data(), sizeof(int32_t) * ctx->h_ids.size(), hipMemcpyHostToDevice, stream));
 
 	const KswTask *d_tasks = (const KswTask *)ctx->tasks.p;
 	const int32_t *d_ids = (const int32_t *)ctx->ids.p;
@@ -318,7 +339,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], (int)ids[GD_KIND_WAVE64].size(), d_qseq, d_tseq, d_bt,
 		                 d_status, d_score, K, stream);
 	if (!ids[GD_KIND_WAVE16].empty())
-		gd_launch_wave16(d_tasks, d_ids + id_off[GD_KIND_WAVE16], (int)ids[GD_KIND_WAVE16].size(), d_qseq, d_tseq, d_bt,
+		gd_launch_wave16(d_tasks, d_ids + id_off[GD_KIND_WAVE16], (int)(quartets.size() / 4), d_qseq, d_tseq, d_bt,
 		                 d_status, d_score, K, stream);
 	if (!ids[GD_KIND_GENERIC].empty()) {
 		const size_t lds = (size_t)max_cap * 7;
@@ -399,6 +420,18 @@ extern "C" int gdiet_hip_ksw_extd2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 			return GDIET_E_CIGAR_CAP;
 		}
 	return GDIET_OK;
+}
+
+// ---- K3: single-affine form ----------------------------------------------------------------------------------
+extern "C" int gdiet_hip_ksw_extz2_batch(gdiet_ctx *ctx, int n, const uint8_t *qseq, const int64_t *qoff, const uint8_t *tseq,
+                                         const int64_t *toff, const int32_t *w, const gdiet_ksw_score_t *sc, int32_t *score,
+                                         int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	if (!sc) { ctx->err = "scoring is NULL"; return GDIET_E_PARAM; }
+	gdiet_ksw_score_t s2 = *sc;
+	s2.q2 = sc->q, s2.e2 = sc->e; // ksw_extz2(q,e) == ksw_extd2(q,e,q,e) cell for cell in APPROX_MAX mode (see include/gdiet_hip.h)
+	return gdiet_hip_ksw_extd2_batch(ctx, n, qseq, qoff, tseq, toff, w, nullptr, &s2, score, n_cigar, cigar, cigar_off);
 }
 
 #include "map_pipeline.hip.h"

@@ -11,10 +11,12 @@
 #include "ksw_common.h"
 #include "ksw_wave_core.h"
 
-// lane l receives the value of lane l-1 (mod 64): DPP wave_ror:1 (GFX9 encoding 0x13C)
-__device__ __forceinline__ u32 gdw_ror1_wave(u32 v)
+// lane l receives the value of lane l-1 (mod LANES): DPP wave_ror:1 (GFX9 encoding 0x13C) for the 64-lane form,
+// row_ror:1 (0x121; a DPP "row" is 16 lanes) for the 16-lane form
+template <int LANES> __device__ __forceinline__ u32 gdw_ror1(u32 v)
 {
-	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false);
+	if (LANES == 64) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false);
+	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);
 }
 
 // the one fresh query byte per anti-diagonal, read through the scalar cache: an aligned dword at a wave-uniform address
@@ -29,6 +31,13 @@ __device__ __forceinline__ u32 gdw_seam_byte(const uint8_t *query, int qlen, int
 	return (wd >> (8 * (a & 3))) & 0xffu;
 }
 
+__device__ __forceinline__ const uint8_t *gdw_uniform_ptr(const uint8_t *p, int src_lane)
+{
+	const uintptr_t a = (uintptr_t)p;
+	const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)a, src_lane), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(a >> 32), src_lane);
+	return (const uint8_t *)((uintptr_t)hi << 32 | lo);
+}
+
 static inline bool gd_wave_scoring_ok(const KswConst &C)
 {
 	WaveK K;
@@ -40,33 +49,49 @@ static inline bool gd_wave_scoring_ok(const KswConst &C)
 
 static inline bool gd_wave_supported(int qlen, int tlen, int w, int lanes)
 {
-	if (lanes != 64) return false; // the 16-lane (4 alignments per wavefront) variant is not wired yet
 	return gd_wave_geometry_ok(qlen, tlen, w, lanes);
 }
 
-__global__ __launch_bounds__(256) void ksw_extd2_wave64_kernel(const KswTask *__restrict__ tasks,
-                                                               const int32_t *__restrict__ task_ids, int n_tasks,
-                                                               const uint8_t *__restrict__ qseq,
-                                                               const uint8_t *__restrict__ tseq,
-                                                               uint8_t *__restrict__ bt, int32_t *__restrict__ status,
-                                                               int32_t *__restrict__ score_out, WaveK K)
+// LANES == 64: one alignment per wavefront (task_ids[slot]).
+// LANES == 16: four alignments OF IDENTICAL GEOMETRY (qlen, tlen, w) per wavefront, one per DPP row of 16 lanes
+//              (task_ids[4*slot + row]; -1 = empty row, which shadows row 0 without storing).  Identical geometry keeps every
+//              band / boundary quantity of the row loop wave-uniform (SGPRs), exactly as in the 64-lane form; only the
+//              sequence and backtrace pointers differ between the rows.  Short reads (150 x 150) all share one geometry.
+template <int LANES>
+__global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
+                                                             const int32_t *__restrict__ task_ids, int n_slots,
+                                                             const uint8_t *__restrict__ qseq,
+                                                             const uint8_t *__restrict__ tseq,
+                                                             uint8_t *__restrict__ bt, int32_t *__restrict__ status,
+                                                             int32_t *__restrict__ score_out, WaveK K)
 {
-	constexpr int LANES = 64;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 63, sub = lane & (LANES - 1), row = LANES == 64 ? 0 : lane >> 4;
 	const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-	if (slot >= n_tasks) return;
-	const int tid = __builtin_amdgcn_readfirstlane(task_ids[slot]);
-	if (__builtin_amdgcn_readfirstlane(status[tid]) != GD_ST_PENDING) return;
+	if (slot >= n_slots) return;
+	int tid, live = 1;
+	if (LANES == 64) {
+		tid = __builtin_amdgcn_readfirstlane(task_ids[slot]);
+		if (__builtin_amdgcn_readfirstlane(status[tid]) != GD_ST_PENDING) return;
+	} else {
+		tid = task_ids[4 * slot + row];
+		const int tid0 = __builtin_amdgcn_readfirstlane(tid);
+		if (tid < 0) tid = tid0, live = 0;
+		else if (status[tid] != GD_ST_PENDING) live = 0; // the exact-match pre-filter answered this one
+		if (!__builtin_amdgcn_ballot_w64(live)) return;
+	}
 	const KswTask *Tp = tasks + tid;
 	const int qlen = __builtin_amdgcn_readfirstlane(Tp->qlen), tlen = __builtin_amdgcn_readfirstlane(Tp->tlen);
 	int w = __builtin_amdgcn_readfirstlane(Tp->w);
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
 	const uint8_t *query = qseq + Tp->qoff, *target = tseq + Tp->toff;
-	uint8_t *p = bt + Tp->bt_off + (size_t)lane * 16;
+	uint8_t *p = bt + Tp->bt_off + (size_t)sub * 16;
 	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+	// wave-uniform copies of the query pointers for the scalar seam load
+	const uint8_t *q0 = gdw_uniform_ptr(query, 0), *q1 = q0, *q2 = q0, *q3 = q0;
+	if (LANES == 16) q1 = gdw_uniform_ptr(query, 16), q2 = gdw_uniform_ptr(query, 32), q3 = gdw_uniform_ptr(query, 48);
 
 	WaveLane L;
-	gdw_load_block(L, K, lane, 0, query, qlen, target, tlen);
+	gdw_load_block(L, K, sub, 0, query, qlen, target, tlen);
 	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
 	for (int r = 0; r <= rend; ++r) {
 		WaveRow W;
@@ -80,9 +105,17 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave64_kernel(const KswTask *__
 		W.set_tr = (W.en0 | 15) >= r;
 		W.ukey = gdw_edge_key(K, r);
 		// (1) row r-1 values of the previous lane, fetched before any lane is touched
-		const u32 pX = gdw_ror1_wave(L.X[7]), pV = gdw_ror1_wave(L.V[7]), pX2 = gdw_ror1_wave(L.X2[7]), pQ = gdw_ror1_wave(L.Qc[3]);
-		// (2) query window advance; the lane whose block fell below the window takes over block +64
-		if (r > 0) gdw_shift_query(L, pQ, L.blk == prev_st_, gdw_seam_byte(query, qlen, r - (prev_st_ << 4)));
+		const u32 pX = gdw_ror1<LANES>(L.X[7]), pV = gdw_ror1<LANES>(L.V[7]), pX2 = gdw_ror1<LANES>(L.X2[7]), pQ = gdw_ror1<LANES>(L.Qc[3]);
+		// (2) query window advance; the lane whose block fell below the window takes over block +LANES
+		if (r > 0) {
+			const int j = r - (prev_st_ << 4);
+			u32 seam = gdw_seam_byte(q0, qlen, j);
+			if (LANES == 16) {
+				const u32 s1 = gdw_seam_byte(q1, qlen, j), s2 = gdw_seam_byte(q2, qlen, j), s3 = gdw_seam_byte(q3, qlen, j);
+				seam = row == 0 ? seam : row == 1 ? s1 : row == 2 ? s2 : s3;
+			}
+			gdw_shift_query(L, pQ, L.blk == prev_st_, seam);
+		}
 		if (advanced && L.blk < W.st_) gdw_load_block(L, K, L.blk + LANES, r, query, qlen, target, tlen);
 		// (3) scalar fix-ups and the score row
 		if (W.set_tr) gdw_reset_tr(L, K, W);
@@ -92,13 +125,13 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave64_kernel(const KswTask *__
 		if (L.blk <= W.en_) {
 			u32 out[4];
 			gdw_compute(L, K, W, pX, pV, pX2, out);
-			*reinterpret_cast<uint4 *>(p + (size_t)r * (LANES * 16)) = make_uint4(out[0], out[1], out[2], out[3]);
+			if (LANES == 64 || live) *reinterpret_cast<uint4 *>(p + (size_t)r * (LANES * 16)) = make_uint4(out[0], out[1], out[2], out[3]);
 		}
 		// (5) score trackers
 		if (r == 0) L.R = gdw_lo(L.V[0]) - K.B1 - K.qe8;
 		else L.R += gdw_lo(L.V[0]) - K.B1;
 		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 15) == 0) {
-			const int h = (int)gdw_ror1_wave((u32)gdw_track_handoff(L));
+			const int h = (int)gdw_ror1<LANES>((u32)gdw_track_handoff(L));
 			if (L.blk == W.en_) L.R = h + gdw_lo(L.U[0]);
 		}
 		if (W.en0 == tlen - 1) {
@@ -110,7 +143,7 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave64_kernel(const KswTask *__
 		}
 		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
 	}
-	if (L.blk == mlast) {
+	if (L.blk == mlast && live) {
 		score_out[tid] = Rf >> 3;
 		status[tid] = GD_ST_DONE;
 	}
@@ -121,7 +154,13 @@ static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, in
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	hipLaunchKernelGGL(ksw_extd2_wave64_kernel, dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+	hipLaunchKernelGGL(ksw_extd2_wave_kernel<64>, dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
 }
-static inline void gd_launch_wave16(const KswTask *, const int32_t *, int, const uint8_t *, const uint8_t *, uint8_t *,
-                                    int32_t *, int32_t *, KswConst, hipStream_t) {}
+// ids: 4 task ids per wavefront (identical geometry; -1 pads an incomplete quartet), n_quartets wavefronts
+static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, int n_quartets, const uint8_t *q, const uint8_t *t,
+                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s)
+{
+	WaveK K;
+	gdw_make_consts(C, K);
+	hipLaunchKernelGGL(ksw_extd2_wave_kernel<16>, dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
+}

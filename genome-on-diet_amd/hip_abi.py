@@ -66,6 +66,7 @@ def load_library():
                                               i32p, i32p, u32p, i64p]
     lib.gdiet_hip_ksw_extd2_batch_dev.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(KswScore),
                                                   vp, vp, vp, vp, i64p, i64p, i32p, vp]
+    lib.gdiet_hip_ksw_extz2_batch.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, C.POINTER(KswScore), i32p, i32p, u32p, i64p]
     _lib = lib
     return lib
 
@@ -154,6 +155,21 @@ class Context:
                                                 None if ex is None else _ptr(ex, C.c_int32), C.byref(score),
                                                 _ptr(sc, C.c_int32), _ptr(nc, C.c_int32), _ptr(cg, C.c_uint32),
                                                 _ptr(coff, C.c_int64))
+        self._check(rc)
+        return sc, [cg[coff[i]:coff[i] + nc[i]].copy() for i in range(n)]
+
+    def ksw_extz2_batch(self, queries, targets, w, score):
+        """single-affine form (ksw_extz2_sse, reference ksw2.h:62); score.q / score.e are the gap costs"""
+        n = len(queries)
+        qbuf, qoff = pack(queries)
+        tbuf, toff = pack(targets)
+        w = np.ascontiguousarray(np.broadcast_to(np.asarray(w, np.int32), (n,)))
+        coff = np.zeros(n + 1, np.int64)
+        coff[1:] = np.cumsum([len(q) + len(t) for q, t in zip(queries, targets)])
+        sc, nc, cg = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(int(coff[-1]) + 1, np.uint32)
+        rc = self.lib.gdiet_hip_ksw_extz2_batch(self._h, n, _ptr(qbuf, C.c_uint8), _ptr(qoff, C.c_int64), _ptr(tbuf, C.c_uint8),
+                                                _ptr(toff, C.c_int64), _ptr(w, C.c_int32), C.byref(score), _ptr(sc, C.c_int32),
+                                                _ptr(nc, C.c_int32), _ptr(cg, C.c_uint32), _ptr(coff, C.c_int64))
         self._check(rc)
         return sc, [cg[coff[i]:coff[i] + nc[i]].copy() for i in range(n)]
 

@@ -53,7 +53,8 @@ int gdiet_hip_init(gdiet_ctx **ctx, int device_ordinal);   /* replaces nothing: 
 void gdiet_hip_destroy(gdiet_ctx *ctx);
 const char *gdiet_hip_strerror(const gdiet_ctx *ctx);       /* text of the last failure on this context */
 int gdiet_hip_device_name(const gdiet_ctx *ctx, char *buf, size_t len);
-/* which kernel variant handled the last batch: bit0 = register-resident wave kernel, bit1 = generic LDS kernel */
+/* which kernel variants handled the last batch: bit0 = register-resident 64-lane wave kernel, bit1 = generic LDS kernel,
+ * bit2 = register-resident 16-lane kernel (four short alignments per wavefront) */
 int gdiet_hip_last_kernel_mask(const gdiet_ctx *ctx);
 
 /* ---- B3: batched banded dual-affine global alignment -------------------------------------------------------
@@ -91,6 +92,19 @@ int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n,
                                   int32_t *d_score, int32_t *d_n_cigar, uint32_t *d_cigar, const int64_t *d_cigar_off,
                                   const int64_t *h_qoff, const int64_t *h_toff, const int32_t *h_w, /* host copies for planning */
                                   void *stream);
+
+/* ---- K3: batched banded SINGLE-affine global alignment -------------------------------------------------------------
+ * Replaces ksw_extz2_sse + ksw_backtrack (SR/ksw2_extz2_sse.c:31-312, SR/ksw2.h:62; BASELINE config 2; not called by the live
+ * mapping path).  Same batch layout and outputs as gdiet_hip_ksw_extd2_batch; sc->q / sc->e are the gap costs, sc->q2 / sc->e2
+ * are ignored, sc->flag must be GDIET_EZ_APPROX_MAX (the only mode GDiet ever passes).  Implementation note: in that mode
+ * ksw_extz2(q,e) and ksw_extd2(q,e,q,e) visit identical cells with identical values (the unsigned bias of extz2 is a
+ * re-labelling), so the batch runs on the dual-affine kernels with both gap models equal; tests pin this against
+ * ksw_extz2_sse's own outputs (tests/golden/ksw2_extz2.npz). */
+int gdiet_hip_ksw_extz2_batch(gdiet_ctx *ctx, int n,
+                              const uint8_t *qseq, const int64_t *qoff,
+                              const uint8_t *tseq, const int64_t *toff,
+                              const int32_t *w, const gdiet_ksw_score_t *sc,
+                              int32_t *score, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off);
 
 /* make sure the context owns at least `bytes` of device workspace (backtrace arena); returns GDIET_E_NOMEM
  * if the device cannot provide it.  gdiet_hip_ksw_extd2_batch() grows the arena by itself. */

@@ -101,3 +101,39 @@ def test_band_exhaustion_reports_neg_inf(gpu_ctx, pkg):
     q = t[:100].copy()
     sc, cg = gpu_ctx.ksw_extd2_batch([q], [t], 20, pkg.KswScore.from_preset("sr"))
     assert sc[0] == pkg.hip_abi.NEG_INF and len(cg[0]) == 0
+
+
+def test_short_read_quartets_match_oracle(gpu_ctx, pkg, oracle):
+    """the 16-lane kernel (four alignments of identical geometry per wavefront): a block of 150 x 150, w = 150 pairs (the
+    short-read shape: SR/map.c:925 passes len, len, bw), incomplete quartets, mixed geometries, Ns, exact-match rows inside a
+    quartet -- all against the oracle"""
+    gdo, lib = oracle
+    rng = np.random.default_rng(77)
+    qs, ts, ws = [], [], []
+    for i in range(403):  # 403 = 100 quartets + 3: the last quartet is padded
+        q, t = gdo.make_pair(rng, 150, 0.02, 0.004, 0.004, n_frac=0.01 if i % 7 == 0 else 0.0)
+        n = min(len(q), len(t), 150)
+        if i % 5:
+            q, t = q[:n], t[:n]  # len x len as the short-read path calls it; every 5th keeps qlen != tlen
+        if i % 11 == 0:
+            q = t.copy()  # exact match row: answered by the pre-filter, its quartet row must stay silent
+        qs.append(q), ts.append(t), ws.append(150)
+    for i in range(120):  # other geometries: singles and pairs end up in padded quartets
+        n = int(rng.integers(40, 230))
+        q, t = gdo.make_pair(rng, n, 0.03, 0.01, 0.01)
+        qs.append(q), ts.append(t), ws.append(int(rng.integers(30, 200)))
+    ex = np.array([len(q) * 2 if len(q) == len(t) else pkg.hip_abi.NEG_INF for q, t in zip(qs, ts)], np.int32)
+    sc, cg = gpu_ctx.ksw_extd2_batch(qs, ts, ws, pkg.KswScore.from_preset("sr"), exact_score=ex)
+    assert gpu_ctx.last_kernel_mask() & 4
+    a, b, q_, e, q2, e2 = gdo.PRESETS["sr"]
+    mat = gdo.score_matrix(a, b)
+    n_exact = 0
+    for i in range(len(qs)):
+        if len(qs[i]) == len(ts[i]) and np.array_equal(qs[i], ts[i]):
+            assert sc[i] == ex[i] and list(cg[i]) == [len(qs[i]) << 4]
+            n_exact += 1
+            continue
+        o = gdo.oracle_extd2(lib, qs[i], ts[i], mat, q_, e, q2, e2, ws[i])
+        assert sc[i] == o["score"], (i, len(qs[i]), len(ts[i]), ws[i], sc[i], o["score"])
+        assert np.array_equal(cg[i], o["cigar"]), (i, len(qs[i]), len(ts[i]), ws[i])
+    assert n_exact >= 30

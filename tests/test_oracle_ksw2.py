@@ -58,3 +58,29 @@ def test_self_alignment_is_all_match(oracle):
         a, b, go, ge, go2, ge2 = gdo.PRESETS["sr"]
         o = gdo.oracle_extd2(lib, t, t, gdo.score_matrix(a, b), go, ge, go2, ge2, 150)
         assert o["score"] == n * a and list(o["cigar"]) == [n << 4]
+
+
+def test_extz2_equals_extd2_with_equal_gap_models(oracle):
+    """the identity K3 rests on (include/gdiet_hip.h): in APPROX_MAX mode ksw_extz2(q,e) and ksw_extd2(q,e,q,e) give the same
+    score, CIGAR and band-exhaustion status -- checked on the oracle (pinned to the reference) and, for the golden extz2
+    vectors, on ksw_extz2_sse's own outputs"""
+    gdo, lib = oracle
+    import pin_ksw2
+    rng = np.random.default_rng(31)
+    n = 0
+    for tag, q, t, preset, w, zdrop, eb, flag in pin_ksw2.cases(rng, 900, heavy=False):
+        if flag != gdo.EZ_APPROX_MAX or zdrop != -1:
+            continue
+        a, b, go, ge, _, _ = gdo.PRESETS[preset]
+        mat = gdo.score_matrix(a, b)
+        z = gdo.oracle_extz2(lib, q, t, mat, go, ge, w)
+        d = gdo.oracle_extd2(lib, q, t, mat, go, ge, go, ge, w)
+        assert z["score"] == d["score"] and z["zdropped"] == d["zdropped"] and np.array_equal(z["cigar"], d["cigar"]), (tag, len(q), len(t), w)
+        n += 1
+    assert n > 700
+    for c in load_ksw("ksw2_extz2"):
+        if c["flag"] != 8 or c["zdrop"] != -1:
+            continue
+        a, b, go, ge, _, _ = gdo.PRESETS[c["preset"]]
+        d = gdo.oracle_extd2(lib, c["q"], c["t"], gdo.score_matrix(a, b), go, ge, go, ge, c["w"])
+        assert d["score"] == c["score"] and np.array_equal(d["cigar"], c["cigar"])
