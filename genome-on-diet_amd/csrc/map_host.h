@@ -31,6 +31,9 @@ struct GdMapOpt {
 	float vt_cov = 0.03f, vt_f = 0.05f, vt_df1 = 0.01f, vt_df2 = 0.01f;
 	uint32_t max_max_gap = 50000, max_min_gap = 4000;
 	float max_seeds = 0.1f;
+	// ShortReads variant only (SR/minimap.h:149-150,196-197, SR/main.c:163-172)
+	float min_cnt = 1.0f, rec_threshold_frac = 0.0f, bw_frac = 0.05f;
+	int32_t bw_min = 500, bw_max = 1500, af_max_loc = 20;
 	GdPattern pat;
 };
 
@@ -575,6 +578,111 @@ static inline void gd_lr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 			const size_t j = out.size() - 1;
 			if (j > 0 && out[j].score > out[j - 1].score) std::swap(out[j], out[j - 1]);
 		}
+	if (!out.empty()) gd_set_sam_params(out, qlen_sum, (unsigned)O.a, (O.flag & GD_F_NO_PRINT_2ND) ? 0u : (unsigned)O.best_n);
+}
+
+// ---- G2: candidate geometry of the ShortReads variant, SR/map.c:779-839 -------------------------------------------------------
+// Turns the voted diagonals into len x len DP boxes; candidates the reference skips (:796-801) are removed, order is kept.
+static inline void gd_sr_boxes(std::vector<GdCand> &C, const GdMapOpt &O, const GdRefView &R, uint32_t qlen_sum)
+{
+	std::vector<GdCand> out;
+	out.reserve(C.size());
+	for (GdCand c : C) {
+		const int str = (int)c.v.str;
+		const uint32_t target_id = c.v.chrom_id;
+		uint32_t start_offset, end_offset;
+		int32_t target_loc = c.v.first_target_loc;
+		if (str) target_loc -= (O.k - 1);
+		int32_t target_start = target_loc, target_end = target_loc;
+		const int32_t tlen = target_id < R.n_seq ? (int32_t)R.seq[target_id].len : 0;
+		if (qlen_sum > 300) {
+			if (c.v.first_query_loc == c.v.last_query_loc) continue;
+			start_offset = c.v.first_query_loc - (uint32_t)(O.k - 1);
+			end_offset = c.v.last_query_loc;
+			if (str) {
+				target_end = (int32_t)((uint32_t)target_end - start_offset);
+				target_start = (int32_t)((uint32_t)target_start - end_offset);
+				if (target_start < 0) {
+					end_offset += (uint32_t)target_start;
+					target_start = 0;
+				}
+			} else {
+				target_start = (int32_t)((uint32_t)target_start + start_offset);
+				target_end = (int32_t)((uint32_t)target_end + end_offset);
+				if (target_end + 1 > tlen) {
+					end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
+					target_end = tlen - 1;
+				}
+			}
+		} else {
+			if (str) {
+				if (target_end > tlen - 1) {
+					start_offset = (uint32_t)(target_end - (tlen - 1));
+					target_end = tlen - 1;
+				} else start_offset = 0;
+				if ((uint32_t)target_end < qlen_sum - start_offset - 1) { // int32 against unsigned: compared as unsigned (:816)
+					end_offset = start_offset + (uint32_t)target_end;
+					target_start = 0;
+				} else {
+					end_offset = qlen_sum - 1;
+					target_start = (int32_t)((uint32_t)target_end - (end_offset - start_offset));
+				}
+			} else {
+				if (target_start < 0) {
+					start_offset = (uint32_t)(-target_start);
+					target_start = 0;
+				} else start_offset = 0;
+				if ((uint32_t)(tlen - target_start) < qlen_sum - start_offset) { // (:831) unsigned compare as well
+					end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
+					target_end = tlen - 1;
+				} else {
+					end_offset = qlen_sum - 1;
+					target_end = (int32_t)((uint32_t)target_start + (end_offset - start_offset));
+				}
+			}
+		}
+		const uint32_t len = end_offset - start_offset + 1;
+		c.target_id = target_id, c.target_start = (uint32_t)target_start, c.target_end = (uint32_t)target_end;
+		c.query_start = start_offset, c.query_end = end_offset, c.qlen = len, c.tlen = len;
+		c.qseq_off = str ? qlen_sum - 1 - end_offset : start_offset; // qs = &qs_rev[qlen_sum-1-end_offset] / &qs_for[start_offset]
+		c.exact_score = qlen_sum < 300 ? (int32_t)(qlen_sum * (uint32_t)O.a) : GD_NEG_INF_SCORE; // :873-908
+		c.valid = 1;
+		out.push_back(c);
+	}
+	C.swap(out);
+}
+
+// ---- SR/map.c:931-984: records after the DP -- mm_update_extra, clip / min_dp_max filter, insertion by score, mapq ------------
+static inline void gd_sr_finish(std::vector<GdCand> &C, const std::vector<GdDpResult> &dp, const GdMapOpt &O, const GdRefView &R,
+                                uint32_t qlen_sum, const uint8_t *enc_for, const uint8_t *enc_rev, std::vector<GdReg> &out)
+{
+	out.clear();
+	const int g = O.a, bb = O.b < 0 ? O.b : -O.b;
+	int8_t mat[25];
+	for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? (int8_t)g : (int8_t)bb);
+	std::vector<uint8_t> tseq;
+	for (size_t i = 0; i < C.size(); ++i) {
+		const GdCand &c = C[i];
+		// a band that emptied leaves score = KSW_NEG_INF and no CIGAR; dp_score < min_dp_max then drops the record (:955-958)
+		if (dp[i].score == GD_NEG_INF_SCORE && O.min_dp_max > GD_NEG_INF_SCORE) continue;
+		GdReg r;
+		r.rid = (int32_t)c.target_id, r.score = dp[i].score, r.qs = (int32_t)c.query_start, r.qe = (int32_t)c.query_end + 1;
+		r.rs = (int32_t)c.target_start, r.re = (int32_t)c.target_end + 1, r.rev = c.v.str;
+		r.has_p = true;
+		r.cigar.assign(dp[i].cigar, dp[i].cigar + (dp[i].n_cigar > 0 ? dp[i].n_cigar : 0));
+		r.dp_score = dp[i].score;
+		tseq.assign((size_t)c.tlen + 16, 0);
+		gd_getseq(R, c.target_id, c.target_start, c.target_end + 1, tseq.data());
+		const uint8_t *qseq = (c.v.str ? enc_rev : enc_for) + c.qseq_off;
+		gd_update_extra(r, qseq, tseq.data(), mat, (int8_t)O.q, (int8_t)O.e, !(O.flag & GD_F_SR));
+		const uint32_t clip0 = r.rev ? qlen_sum - r.qe : (uint32_t)r.qs, clip1 = r.rev ? (uint32_t)r.qs : qlen_sum - r.qe;
+		if (!(clip0 < qlen_sum && clip1 < qlen_sum) || r.dp_score < O.min_dp_max) continue;
+		out.push_back(r);
+		for (size_t k = out.size() - 1; k > 0; k--) { // full insertion by descending score (:965-973)
+			if (out[k].score > out[k - 1].score) std::swap(out[k], out[k - 1]);
+			else break;
+		}
+	}
 	if (!out.empty()) gd_set_sam_params(out, qlen_sum, (unsigned)O.a, (O.flag & GD_F_NO_PRINT_2ND) ? 0u : (unsigned)O.best_n);
 }
 

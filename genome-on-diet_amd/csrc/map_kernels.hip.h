@@ -16,6 +16,8 @@ struct MapDevOpt { // uniform per batch
 	uint32_t max_nb_seeds; // cap of mm_sketch3 (UINT32_MAX unless frag mode)
 	int64_t flag;
 	GdLrVoteOpt vote;
+	GdSrVoteOpt sr;    // ShortReads variant (flag & MM_F_SR)
+	int32_t is_sr, pad;
 	GdPattern pat;
 };
 
@@ -31,7 +33,7 @@ struct MapSeedOut {
 	int32_t n_seeds;  // kept seeds (< 0: scratch overflow)
 	int32_t shift;
 	uint32_t tel;     // tmp_extracted_len
-	uint32_t pad;
+	uint32_t n_mv;    // mv.n after mm_seed_mz_flt (the ShortReads vote thresholds scale with it, SR/map.c:667-676)
 	int64_t n_a;      // total occurrences of the kept seeds
 };
 
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(64) void map_seed_kernel(int n_reads, const uint8_t
 	const uint8_t *str = reads + roff[rid];
 	const int len = (int)(roff[rid + 1] - roff[rid]);
 	MapSeedOut o;
-	o.n_seeds = 0, o.shift = 0, o.tel = (uint32_t)len, o.pad = 0, o.n_a = 0;
+	o.n_seeds = 0, o.shift = 0, o.tel = (uint32_t)len, o.n_mv = 0, o.n_a = 0;
 	if (len <= 0) { out[rid] = o; return; }
 	const MapReadScratch S = sc[rid];
 	GdMini *mv = mv_arena + S.mv_off;
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(64) void map_seed_kernel(int n_reads, const uint8_t
 	o.tel = gd_sketch3(str, (unsigned)len, O.w, O.k, O.pat, o.shift, O.max_nb_seeds, mv, S.mv_cap, &n_mv);
 	if (n_mv == ~0u) { o.n_seeds = -1; out[rid] = o; return; }
 	if (O.q_occ_frac > 0.0f) n_mv = gd_mz_flt(mv, n_mv, O.mid_occ, O.q_occ_frac, u64_arena + S.u64_off);
+	o.n_mv = n_mv;
 	o.n_seeds = gd_collect_matches2(I, mv, n_mv, len, O.mid_occ, O.max_max_occ, O.occ_dist, seed_arena + S.seed_off, &o.n_a);
 	out[rid] = o;
 }
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(64) void map_vote_kernel(int n_reads, const int64_t
 	GdLoc *sf = gd_sort_locs(a_for, tmp, nf);
 	if (sf != a_for) for (unsigned i = 0; i < nf; ++i) a_for[i] = sf[i];
 	GdLoc *sr = gd_sort_locs(a_rev, tmp, nr);
-	o.n_cand = gd_lr_candidates(a_for, nf, sr, nr, (uint32_t)len, (int32_t)so.tel, O.vote, o.cand);
+	if (O.is_sr) o.n_cand = gd_sr_candidates(a_for, nf, sr, nr, (uint32_t)len, so.tel, so.n_mv, O.sr, o.cand);
+	else o.n_cand = gd_lr_candidates(a_for, nf, sr, nr, (uint32_t)len, (int32_t)so.tel, O.vote, o.cand);
 }
 
 // one DP box: where its query / target windows come from and where they go in the packed ksw batch buffers
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	const uint8_t *str = reads + roff[rid];
 	const int len = (int)(roff[rid + 1] - roff[rid]);
 	MapSeedOut o;
-	o.n_seeds = 0, o.shift = 0, o.tel = (uint32_t)len, o.pad = 0, o.n_a = 0;
+	o.n_seeds = 0, o.shift = 0, o.tel = (uint32_t)len, o.n_mv = 0, o.n_a = 0;
 	if (len <= 0) { if (lane == 0) out[rid] = o; return; }
 	const MapReadScratch S = sc[rid];
 	GdMini *mv = mv_arena + S.mv_off;
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	for (unsigned j = lane; j < n_mv; j += 64) gd_collect_probe(I, mv[j], seeds[j]);
 	__syncthreads();
 	if (lane == 0) {
+		o.n_mv = n_mv;
 		o.n_seeds = gd_collect_finish(seeds, (int)n_mv, len, O.mid_occ, O.max_max_occ, O.occ_dist, &o.n_a);
 		out[rid] = o;
 	}

@@ -228,6 +228,8 @@ static void gd_opt_from_c(const gdiet_mapopt_t *o, const gdiet_index *ix, GdMapO
 	O.max_max_occ = o->max_max_occ, O.occ_dist = o->occ_dist, O.max_frag_len = o->max_frag_len, O.vt_dis = o->vt_dis, O.vt_nb_loc = o->vt_nb_loc;
 	O.vt_cov = o->vt_cov, O.vt_f = o->vt_f, O.vt_df1 = o->vt_df1, O.vt_df2 = o->vt_df2, O.max_max_gap = o->max_max_gap, O.max_min_gap = o->max_min_gap;
 	O.max_seeds = o->max_seeds, O.pat = ix->h.pat;
+	O.min_cnt = o->min_cnt, O.rec_threshold_frac = o->rec_threshold_frac, O.bw_frac = o->bw_frac, O.bw_min = o->bw_min, O.bw_max = o->bw_max;
+	O.af_max_loc = o->AF_max_loc;
 }
 
 // a contiguous slice of a resident read batch
@@ -271,6 +273,10 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	D.flag = O.flag, D.pat = O.pat;
 	D.vote.vt_dis = O.vt_dis, D.vote.vt_nb_loc = O.vt_nb_loc, D.vote.bw = O.bw, D.vote.vt_cov = O.vt_cov, D.vote.vt_f = O.vt_f;
 	D.vote.vt_df1 = O.vt_df1, D.vote.vt_df2 = O.vt_df2, D.vote.k = O.k;
+	const bool is_sr = (O.flag & GD_F_SR) != 0;
+	D.is_sr = is_sr, D.pad = 0;
+	D.sr.min_cnt = O.min_cnt, D.sr.rec_threshold_frac = O.rec_threshold_frac, D.sr.bw_frac = O.bw_frac, D.sr.bw_min = O.bw_min, D.sr.bw_max = O.bw_max;
+	D.sr.af_max_loc = O.af_max_loc, D.sr.max_nb_seeds = D.max_nb_seeds, D.sr.frag_mode = (O.flag & GD_F_FRAG_MODE) != 0;
 	const uint8_t *d_reads = (const uint8_t *)B.d_reads;
 	const int64_t *d_roff = (const int64_t *)B.d_roff;
 	ctx->stage_s[5] += gd_now() - t0, t0 = gd_now();
@@ -308,7 +314,8 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		if (!nc) return;
 		cand[i].resize(nc);
 		for (unsigned j = 0; j < nc; ++j) cand[i][j].v = vo[i].cand[j];
-		gd_lr_link_and_boxes(cand[i], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
+		if (is_sr) gd_sr_boxes(cand[i], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
+		else gd_lr_link_and_boxes(cand[i], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
 	});
 	std::vector<int> box_first(n + 1, 0);
 	for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + (int)cand[i].size();
@@ -337,7 +344,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			M.q_dst = qoff[b], M.t_dst = toff[b];
 			qoff[b + 1] = qoff[b] + c.qlen, toff[b + 1] = toff[b] + c.tlen;
 			coff[b + 1] = coff[b] + c.qlen + c.tlen;
-			bw[b] = (int32_t)O.bw, ex[b] = c.exact_score;
+			bw[b] = is_sr ? (int32_t)gd_sr_bw((int)rl, D.sr) : (int32_t)O.bw, ex[b] = c.exact_score; // SR/map.c:624-631,925 ; LR/map.c:1800
 		}
 	if (bad_box) { ctx->err = "degenerate DP box (candidate window outside the read/contig); the reference's behaviour is undefined there"; return GDIET_E_PARAM; }
 	ctx->stage_s[2] += gd_now() - t0, t0 = gd_now();
@@ -399,7 +406,8 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig.data() + poff[b];
 		}
 		std::vector<GdReg> out;
-		gd_lr_finish(cand[i], dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
+		if (is_sr) gd_sr_finish(cand[i], dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
+		else gd_lr_finish(cand[i], dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
 		gd_regs_out(out, &n_regs[i], &regs[i]);
 	});
 	ctx->stage_s[4] += gd_now() - t0;
@@ -424,8 +432,9 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	if (n == 0) return GDIET_OK;
 	GdMapOpt O;
 	gd_opt_from_c(copt, ix, O);
-	if (O.flag & GD_F_SR) { ctx->err = "the ShortReads variant of mm_map_frag is not implemented yet (LongReads only)"; return GDIET_E_PARAM; }
-	if (O.vt_nb_loc + 2 > GDM_MAX_VT) { ctx->err = "vt_nb_loc too large"; return GDIET_E_PARAM; }
+	if (O.flag & GD_F_SR) {
+		if (O.af_max_loc < 1 || O.af_max_loc > GDM_MAX_VT) { ctx->err = "AF_max_loc must be in [1," + std::to_string(GDM_MAX_VT) + "]"; return GDIET_E_PARAM; }
+	} else if (O.vt_nb_loc + 2 > GDM_MAX_VT) { ctx->err = "vt_nb_loc too large"; return GDIET_E_PARAM; }
 	if (O.mid_occ <= 0) { ctx->err = "mid_occ must be set (mm_mapopt_update)"; return GDIET_E_PARAM; }
 	const int lanes = std::max(1, std::min(ctx->map_lanes, (n + 255) / 256));
 	if (lanes == 1) {

@@ -544,7 +544,7 @@ struct GdLrVoteOpt {
 	int32_t k;
 };
 
-#define GDM_MAX_VT 16 // vt_nb_loc + 2 must fit
+#define GDM_MAX_VT 24 // vt_nb_loc + 2 (LongReads) / AF_max_loc (ShortReads, default 20) must fit
 
 // seqs[] must hold vt_nb_loc+2 entries.  Returns the number of candidates (0: unmapped).
 GDM_HD unsigned gd_lr_candidates(const GdLoc *a_for, unsigned n_for, const GdLoc *a_rev, unsigned n_rev, uint32_t qlen_sum,
@@ -593,6 +593,95 @@ GDM_HD unsigned gd_lr_candidates(const GdLoc *a_for, unsigned n_for, const GdLoc
 				v2.last_target_loc = (int32_t)((double)(uint32_t)(v2.first_target_loc + v2.last_query_loc - v2.first_query_loc) + 0.5 * (double)O.bw);
 			seqs[nb++] = v2;
 		}
+	}
+	return nb;
+}
+
+// ---- V2: vote, ShortReads (SR/map.c:447-584): threshold on the hit COUNT of a run, one recovery candidate ----------------------
+struct GdSrVoteOpt {
+	float min_cnt, rec_threshold_frac, bw_frac; // -n FLOAT1,FLOAT2 ; -r FLOAT,..
+	int32_t bw_min, bw_max, af_max_loc;         // -r ..,INT,INT ; --AF_max_loc
+	uint32_t max_nb_seeds;                      // frag mode cap of mm_sketch3 (SR/map.c:621-622), UINT32_MAX otherwise
+	int32_t frag_mode;
+};
+
+// band width = vote distance of one read, SR/map.c:624-631 (float product truncated to unsigned, then clamped with the
+// int bounds converted to unsigned)
+GDM_HD uint32_t gd_sr_bw(int qlen, const GdSrVoteOpt &O)
+{
+	uint32_t bw = (uint32_t)(float)((float)qlen * O.bw_frac);
+	if ((uint32_t)O.bw_min > bw) bw = (uint32_t)O.bw_min;
+	else if ((uint32_t)O.bw_max < bw) bw = (uint32_t)O.bw_max;
+	return bw;
+}
+
+// In GdVt the ShortReads vt_t (SR/map.c:431-440) keeps target_loc in first_target_loc; last_target_loc is unused (0).
+GDM_HD void gd_sr_vt_set(GdVt &v, uint64_t target_loc, uint32_t fq, uint32_t lq, int str, unsigned counter, uint32_t tel)
+{
+	// (int32)(target_loc & UINT32_MAX) + (str ? extracted_len : -(extracted_len + tmp_extracted_len)) with extracted_len = 0
+	// (:502-504; the unsigned negation wraps, the sum is then converted back to int32)
+	v.chrom_id = (uint32_t)(target_loc >> 32);
+	v.first_target_loc = str ? (int32_t)(uint32_t)target_loc : (int32_t)((uint32_t)target_loc - tel);
+	v.last_target_loc = 0, v.first_query_loc = fq, v.last_query_loc = lq, v.str = (uint32_t)str, v.score = counter;
+}
+
+GDM_HD void gd_sr_vt_close(GdVt *pot, unsigned &out_len, GdVt &recovery, unsigned counter, uint64_t target_loc, uint32_t fq, uint32_t lq,
+                           int str, uint32_t tel, unsigned vt_threshold, unsigned max_n, unsigned vt_rec_threshold)
+{
+	if (counter > vt_threshold) {
+		if (out_len == max_n) {
+			if (pot[out_len - 1].score >= counter) return;
+		} else out_len++;
+		gd_sr_vt_set(pot[out_len - 1], target_loc, fq, lq, str, counter, tel);
+		for (unsigned k = out_len - 1; k > 0; k--) {
+			if (pot[k].score > pot[k - 1].score) { GdVt t = pot[k]; pot[k] = pot[k - 1]; pot[k - 1] = t; }
+			else break;
+		}
+	} else if (out_len == 0 && counter > vt_rec_threshold && counter > recovery.score)
+		gd_sr_vt_set(recovery, target_loc, fq, lq, str, counter, tel);
+}
+
+GDM_HD void gd_vote_sr(const GdLoc *loc, unsigned len, int str, GdVt *pot, unsigned *nb, uint32_t vt_distance, uint32_t tel, GdVt &recovery,
+                       unsigned vt_threshold, unsigned max_n, unsigned vt_rec_threshold)
+{
+	if (len == 0) return;
+	unsigned out_len = *nb, counter = 1;
+	uint64_t target_loc = loc[0].target;
+	uint32_t fq = loc[0].query, lq = loc[0].query;
+	for (unsigned i = 1; i < len; i++) {
+		const GdLoc cur = loc[i];
+		if (cur.target - target_loc <= vt_distance) {
+			counter++;
+			if (cur.query < fq) target_loc = cur.target, fq = cur.query;
+			if (cur.query > lq) lq = cur.query;
+		} else {
+			gd_sr_vt_close(pot, out_len, recovery, counter, target_loc, fq, lq, str, tel, vt_threshold, max_n, vt_rec_threshold);
+			target_loc = cur.target, fq = lq = cur.query, counter = 1;
+		}
+	}
+	gd_sr_vt_close(pot, out_len, recovery, counter, target_loc, fq, lq, str, tel, vt_threshold, max_n, vt_rec_threshold);
+	*nb = out_len;
+}
+
+// the candidate list of one short read, SR/map.c:664-699; n_mv = mv.n after mm_seed_mz_flt.  pot[] holds af_max_loc entries.
+GDM_HD unsigned gd_sr_candidates(const GdLoc *a_for, unsigned n_for, const GdLoc *a_rev, unsigned n_rev, uint32_t qlen_sum, uint32_t tel,
+                                 uint32_t n_mv, const GdSrVoteOpt &O, GdVt *pot)
+{
+	const bool frag = O.frag_mode && tel < qlen_sum;
+	unsigned vt_threshold = frag ? (unsigned)((float)O.max_nb_seeds * O.min_cnt) : (unsigned)((float)n_mv * O.min_cnt);
+	const unsigned vt_rec_threshold = frag ? (unsigned)((float)O.max_nb_seeds * O.rec_threshold_frac) : (unsigned)((float)n_mv * O.rec_threshold_frac);
+	if (vt_threshold == 0) vt_threshold = 1;
+	const uint32_t bw = gd_sr_bw((int)qlen_sum, O);
+	GdVt recovery;
+	recovery.chrom_id = 0, recovery.first_target_loc = recovery.last_target_loc = 0, recovery.first_query_loc = recovery.last_query_loc = 0;
+	recovery.score = 0, recovery.str = 0;
+	unsigned nb = 0;
+	gd_vote_sr(a_for, n_for, 0, pot, &nb, bw, tel, recovery, vt_threshold, (unsigned)O.af_max_loc, vt_rec_threshold);
+	gd_vote_sr(a_rev, n_rev, 1, pot, &nb, bw, tel, recovery, vt_threshold, (unsigned)O.af_max_loc, vt_rec_threshold);
+	if (nb == 0) {
+		if (recovery.score == 0) return 0;
+		pot[0] = recovery;
+		nb = 1;
 	}
 	return nb;
 }

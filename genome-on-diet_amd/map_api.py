@@ -11,6 +11,7 @@ import numpy as np
 from .hip_abi import GdietError, load_library
 
 F_NO_PRINT_2ND = 0x4000
+F_SR, F_FRAG_MODE = 0x1000, 0x2000
 
 
 class MapOpt(C.Structure):
@@ -18,7 +19,9 @@ class MapOpt(C.Structure):
                 ("e2", C.c_int32), ("bw", C.c_uint32), ("min_dp_max", C.c_int32), ("best_n", C.c_int32), ("q_occ_frac", C.c_float),
                 ("mid_occ", C.c_int32), ("max_max_occ", C.c_int32), ("occ_dist", C.c_int32), ("max_frag_len", C.c_int32),
                 ("vt_dis", C.c_uint32), ("vt_nb_loc", C.c_uint32), ("vt_cov", C.c_float), ("vt_f", C.c_float), ("vt_df1", C.c_float),
-                ("vt_df2", C.c_float), ("max_max_gap", C.c_uint32), ("max_min_gap", C.c_uint32), ("max_seeds", C.c_float)]
+                ("vt_df2", C.c_float), ("max_max_gap", C.c_uint32), ("max_min_gap", C.c_uint32), ("max_seeds", C.c_float),
+                ("min_cnt", C.c_float), ("rec_threshold_frac", C.c_float), ("bw_frac", C.c_float), ("bw_min", C.c_int32), ("bw_max", C.c_int32),
+                ("AF_max_loc", C.c_int32)]
 
 
 class Reg(C.Structure):
@@ -36,6 +39,12 @@ PRESETS = {
     "ont": dict(k=15, w=10, Z="10", W=2, a=2, b=4, q=4, e=2, q2=24, e2=1, bw=1300, min_dp_max=35000, best_n=1, max_seeds=0.2,
                 vt_dis=1000, vt_nb_loc=3, vt_df1=0.007, vt_df2=0.007, vt_cov=0.3, vt_f=0.04, max_min_gap=4000, max_max_gap=50000,
                 occ_dist=500, min_mid_occ=10, max_mid_occ=1000000, flag=0),
+    # README.md:41: -ax sr -Z 10 -W 2 -i 2 -k 21 -w 11 -N 1 -r 0.05,150,200 -n 0.95,0.3 -s 100 --AF_max_loc 2 --secondary=yes
+    # (preset options.c:130-148: flag SR|FRAG_MODE|HEAP_SORT, NO_PRINT_2ND cleared by --secondary=yes; mid_occ fixed at 1000)
+    "sr": dict(k=21, w=11, Z="10", W=2, a=2, b=8, q=12, e=2, q2=24, e2=1, bw=0, min_dp_max=100, best_n=1, max_seeds=2.0,
+               vt_dis=0, vt_nb_loc=0, vt_df1=0.0, vt_df2=0.0, vt_cov=0.0, vt_f=0.0, max_min_gap=0, max_max_gap=0,
+               occ_dist=500, mid_occ=1000, min_mid_occ=0, max_mid_occ=0, flag=F_SR | F_FRAG_MODE, max_frag_len=800,
+               min_cnt=0.95, rec_threshold_frac=0.3, bw_frac=0.05, bw_min=150, bw_max=200, AF_max_loc=2),
 }
 
 
@@ -165,9 +174,11 @@ class Mapper:
         self.mid_occ = mid
         self.opt = MapOpt(flag=p["flag"], a=p["a"], b=p["b"], q=p["q"], e=p["e"], q2=p["q2"], e2=p["e2"], bw=p["bw"],
                           min_dp_max=p["min_dp_max"], best_n=p["best_n"], q_occ_frac=0.01, mid_occ=mid, max_max_occ=4095,
-                          occ_dist=p["occ_dist"], max_frag_len=0, vt_dis=p["vt_dis"], vt_nb_loc=p["vt_nb_loc"], vt_cov=p["vt_cov"],
+                          occ_dist=p["occ_dist"], max_frag_len=p.get("max_frag_len", 0), vt_dis=p["vt_dis"], vt_nb_loc=p["vt_nb_loc"], vt_cov=p["vt_cov"],
                           vt_f=p["vt_f"], vt_df1=p["vt_df1"], vt_df2=p["vt_df2"], max_max_gap=p["max_max_gap"],
-                          max_min_gap=p["max_min_gap"], max_seeds=p["max_seeds"])
+                          max_min_gap=p["max_min_gap"], max_seeds=p["max_seeds"], min_cnt=p.get("min_cnt", 1.0),
+                          rec_threshold_frac=p.get("rec_threshold_frac", 0.0), bw_frac=p.get("bw_frac", 0.05), bw_min=p.get("bw_min", 500),
+                          bw_max=p.get("bw_max", 1500), AF_max_loc=p.get("AF_max_loc", 20))
 
     def close(self):
         if self._idx:

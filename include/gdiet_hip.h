@@ -121,7 +121,7 @@ int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *backtrack_ms);
  * SURVEY.md 8d = cells + (qlen+tlen) + qlen + ceil(tlen/2) per alignment (what bench.py's roofline divides by the kernel time) */
 int gdiet_hip_last_dp_work(const gdiet_ctx *ctx, uint64_t *cells, uint64_t *alg_bytes);
 
-/* ---- B1: the per-read mapping path for a whole batch of reads (LongReads variant) -----------------------------
+/* ---- B1: the per-read mapping path for a whole batch of reads (LongReads variant; ShortReads variant with MM_F_SR) ----
  * Replaces step 1 of worker_pipeline -- kt_for(n_threads, worker_for, ...) -> mm_map_frag() per read
  * (LR/map.c:2132-2137 -> :1975-2022 -> :1273-1940): sketch2/get_shift/sketch3, seed filter + collect, hit sort,
  * vote/vote_2, candidate geometry, exact-match / ksw_extd2 / backtrack, mm_update_extra, concatenate_cigars,
@@ -157,7 +157,7 @@ uint64_t gdiet_hip_index_n_keys(const gdiet_index *idx);
 
 /* the fields of mm_mapopt_t (LR/minimap.h:145-214) this path reads; fill them from the reference's struct */
 typedef struct {
-	int64_t flag;                 /* MM_F_* bits; only NO_PRINT_2ND, SR, FRAG_MODE, FOR_ONLY, REV_ONLY are interpreted */
+	int64_t flag;                 /* MM_F_* bits; only NO_PRINT_2ND, SR (selects the variant), FRAG_MODE, FOR_ONLY, REV_ONLY are interpreted */
 	int32_t a, b, q, e, q2, e2;
 	uint32_t bw;
 	int32_t min_dp_max, best_n;
@@ -167,6 +167,11 @@ typedef struct {
 	float vt_cov, vt_f, vt_df1, vt_df2;
 	uint32_t max_max_gap, max_min_gap;
 	float max_seeds;
+	/* read only when flag has MM_F_SR: the ShortReads variant of mm_map_frag (SR/map.c:586-984; SR/minimap.h:149-150,196-197) */
+	float min_cnt, rec_threshold_frac;  /* -n FLOAT1,FLOAT2 */
+	float bw_frac;                      /* -r FLOAT,INT,INT: band = vote distance = clamp(qlen*bw_frac, bw_min, bw_max) */
+	int32_t bw_min, bw_max;
+	int32_t AF_max_loc;                 /* --AF_max_loc */
 } gdiet_mapopt_t;
 
 /* one alignment record: mm_reg1_t + mm_extra_t (LR/minimap.h:105-131) flattened */

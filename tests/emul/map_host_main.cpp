@@ -60,7 +60,17 @@ int main(int argc, char **argv)
 	int W = 2;
 	O.flag = GD_F_NO_PRINT_2ND * 0;
 	std::vector<const char *> pos;
-	bool preset_seen = false;
+	bool preset_seen = false, sr_variant = false;
+	auto preset = [&](const char *p) -> bool {
+		if (!strcmp(p, "map-hifi")) { O.k = 19, O.w = 19, O.a = 1, O.b = 4, O.q = 6, O.q2 = 26, O.e = 2, O.e2 = 1, O.occ_dist = 500, min_mid_occ = 50, max_mid_occ = 500; }
+		else if (!strcmp(p, "map-ont")) {}
+		else if (!strcmp(p, "sr") || !strcmp(p, "short")) { // SR/options.c:130-148
+			sr_variant = true;
+			O.k = 21, O.w = 11, O.flag |= GD_F_SR | GD_F_FRAG_MODE | GD_F_NO_PRINT_2ND;
+			O.a = 2, O.b = 8, O.q = 12, O.e = 2, O.q2 = 24, O.e2 = 1, O.max_frag_len = 800, O.min_dp_max = 40, O.best_n = 20, O.mid_occ = 1000;
+		} else return false;
+		return true;
+	};
 	for (int pass = 0; pass < 2; ++pass) { // pass 0: -x only (as the reference does), pass 1: everything else
 		for (int i = 1; i < argc; ++i) {
 			std::string a = argv[i];
@@ -75,17 +85,13 @@ int main(int argc, char **argv)
 				const char *p = argv[++i];
 				if (pass == 0) {
 					preset_seen = true;
-					if (!strcmp(p, "map-hifi")) { O.k = 19, O.w = 19, O.a = 1, O.b = 4, O.q = 6, O.q2 = 26, O.e = 2, O.e2 = 1, O.occ_dist = 500, min_mid_occ = 50, max_mid_occ = 500; }
-					else if (!strcmp(p, "map-ont")) {}
-					else { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
+					if (!preset(p)) { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
 				}
 			} else if (a[0] == '-' && a.size() > 2 && a[1] == 'a' && a[2] == 'x') { // -ax <preset>
 				const char *p = argv[++i];
 				if (pass == 0) {
 					preset_seen = true;
-					if (!strcmp(p, "map-hifi")) { O.k = 19, O.w = 19, O.a = 1, O.b = 4, O.q = 6, O.q2 = 26, O.e = 2, O.e2 = 1, O.occ_dist = 500, min_mid_occ = 50, max_mid_occ = 500; }
-					else if (!strcmp(p, "map-ont")) {}
-					else { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
+					if (!preset(p)) { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
 				}
 			} else if (a == "-t" || a == "-o") ++i;
 			else if (a == "-a") {}
@@ -94,7 +100,23 @@ int main(int argc, char **argv)
 			else if (a == "-Z") { v = argv[++i]; if (pass) Z = v; }
 			else if (a == "-W") { v = argv[++i]; if (pass) W = atoi(v); }
 			else if (a == "-i") { v = argv[++i]; if (pass) { O.max_seeds = (float)strtod(v, 0); if (O.max_seeds < 0) O.max_seeds = 0.1f; } }
-			else if (a == "-r") { v = argv[++i]; if (pass) O.bw = (uint32_t)strtoul(v, 0, 10); }
+			else if (a == "-r") {
+				v = argv[++i];
+				if (pass && !sr_variant) O.bw = (uint32_t)strtoul(v, 0, 10);
+				else if (pass) { // SR/main.c:419-432
+					char *e;
+					const double x = strtod(v, &e);
+					if (x < 1.0) {
+						O.bw_frac = (float)x;
+						if (*e == ',') { O.bw_min = (int)strtol(e + 1, &e, 10); if (*e == ',') O.bw_max = (int)strtol(e + 1, &e, 10); }
+					} else O.bw = (uint32_t)(int)(x + .499);
+				}
+			}
+			else if (a == "-n") { // SR/main.c: -n FLOAT[,FLOAT]
+				v = argv[++i];
+				if (pass) { char *e; O.min_cnt = strtof(v, &e); if (*e == ',') O.rec_threshold_frac = strtof(e + 1, &e); }
+			}
+			else if ((v = val("AF_max_loc"))) { if (pass) O.af_max_loc = (int)atof(v); }
 			else if (a == "-s") { v = argv[++i]; if (pass) O.min_dp_max = atoi(v); }
 			else if (a == "-N") { v = argv[++i]; if (pass) O.best_n = atoi(v); }
 			else if (a.compare(0, 2, "-F") == 0) { if (a.size() == 2) ++i; }
@@ -113,7 +135,9 @@ int main(int argc, char **argv)
 		}
 		if (pass == 0) { // GDiet-forced values after the preset (LR/main.c:169-185)
 			O.max_seeds = 0.1f, O.vt_dis = 100, O.vt_nb_loc = 3, O.vt_cov = 0.03f, O.vt_df1 = 0.01f, O.vt_df2 = 0.01f, O.vt_f = 0.05f;
-			O.max_max_gap = 50000, O.min_dp_max = 40, O.max_min_gap = 4000;
+			O.max_max_gap = 50000, O.max_min_gap = 4000;
+			if (!sr_variant) O.min_dp_max = 40;
+			else O.min_cnt = 1.0f, O.rec_threshold_frac = 0.0f, O.af_max_loc = 20, O.bw = 0, O.bw_min = 500, O.bw_max = 1500, O.bw_frac = 0.05f; // SR/main.c:163-172, SR/options.c:24
 		}
 	}
 	(void)preset_seen;
@@ -168,12 +192,16 @@ int main(int argc, char **argv)
 			GdLoc *sr = gd_sort_locs(ar.data(), tmp.data(), nr);
 			std::vector<GdLoc> srv(sr, sr + nr);
 			GdLrVoteOpt VO = {O.vt_dis, O.vt_nb_loc, O.bw, O.vt_cov, O.vt_f, O.vt_df1, O.vt_df2, O.k};
+			GdSrVoteOpt SO = {O.min_cnt, O.rec_threshold_frac, O.bw_frac, O.bw_min, O.bw_max, O.af_max_loc, cap, (O.flag & GD_F_FRAG_MODE) != 0};
 			GdVt vts[GDM_MAX_VT];
-			const unsigned nc = gd_lr_candidates(sfv.data(), nf, srv.data(), nr, (uint32_t)len, (int32_t)tel, VO, vts);
+			unsigned nc = sr_variant ? gd_sr_candidates(sfv.data(), nf, srv.data(), nr, (uint32_t)len, tel, n_mv, SO, vts)
+			                         : gd_lr_candidates(sfv.data(), nf, srv.data(), nr, (uint32_t)len, (int32_t)tel, VO, vts);
+			const int dp_bw = sr_variant ? (int)gd_sr_bw(len, SO) : (int)O.bw;
 			if (nc > 0) {
 				std::vector<GdCand> C(nc);
 				for (unsigned i = 0; i < nc; ++i) C[i].v = vts[i];
-				gd_lr_link_and_boxes(C, O, R, (uint32_t)len);
+				if (sr_variant) gd_sr_boxes(C, O, R, (uint32_t)len), nc = (unsigned)C.size();
+				else gd_lr_link_and_boxes(C, O, R, (uint32_t)len);
 				std::vector<GdDpResult> dp(nc);
 				std::vector<gdo_extz_t> ez(nc);
 				std::vector<uint32_t> one(nc);
@@ -187,11 +215,12 @@ int main(int argc, char **argv)
 					if (c.exact_score != GD_NEG_INF_SCORE) exact = gdo_exact_match((int)c.qlen, q, (int)c.tlen, t.data()) != 0;
 					if (exact) one[i] = c.qlen << 4, dp[i] = {c.exact_score, &one[i], 1};
 					else {
-						gdo_ksw_extd2((int)c.qlen, q, (int)c.tlen, t.data(), 5, mat, (int8_t)O.q, (int8_t)O.e, (int8_t)O.q2, (int8_t)O.e2, (int)O.bw, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez[i]);
+						gdo_ksw_extd2((int)c.qlen, q, (int)c.tlen, t.data(), 5, mat, (int8_t)O.q, (int8_t)O.e, (int8_t)O.q2, (int8_t)O.e2, dp_bw, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez[i]);
 						dp[i] = {ez[i].score, ez[i].cigar, ez[i].n_cigar};
 					}
 				}
-				gd_lr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs);
+				if (sr_variant) gd_sr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs);
+				else gd_lr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs);
 				for (unsigned i = 0; i < nc; ++i) free(ez[i].cigar);
 			}
 		}

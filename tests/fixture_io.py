@@ -1,8 +1,14 @@
-"""readers for the committed LongReads fixtures (tests/golden/lr/*; made by tools/synth.py + the reference binary)"""
+"""readers for the committed mapping fixtures (tests/golden/lr/*, tests/golden/sr/*; inputs made by tools/synth.py /
+tools/synth_sr_var.py, golden SAM by the reference binaries oracle/_ref/gdiet_{lr,sr}_avx with the command in *.cmd)"""
 import gzip
 import os
 
 LR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lr")
+SR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sr")
+# kind -> (directory, read set / golden stem, Mapper preset)
+SETS = {"hifi": (LR, "hifi", "hifi"), "ont": (LR, "ont", "ont"), "sr": (SR, "sr", "sr"), "sr_var": (SR, "var", "sr")}
+# options of var.cmd that differ from the sr preset (README command): -N 5 -n 0.3,0.1 -s 40 --AF_max_loc 20
+OVERRIDES = {"sr_var": dict(best_n=5, min_cnt=0.3, rec_threshold_frac=0.1, min_dp_max=40, AF_max_loc=20)}
 
 
 def read_fasta(path):
@@ -28,4 +34,5 @@ def read_fastq(path):
 
 
 def golden_sam(kind):
-    return [l.rstrip("\n") for l in gzip.open(os.path.join(LR, kind + ".golden.sam.gz"), "rt")]
+    d, stem, _ = SETS[kind]
+    return [l.rstrip("\n") for l in gzip.open(os.path.join(d, stem + ".golden.sam.gz"), "rt")]

@@ -5,16 +5,17 @@ import os
 
 import pytest
 
-from fixture_io import LR, golden_sam, read_fasta, read_fastq
+from fixture_io import LR, OVERRIDES, SETS, golden_sam, read_fasta, read_fastq
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont"])
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var"])
 def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
-    names, seqs = read_fasta(os.path.join(LR, "ref.fa.gz"))
-    reads = read_fastq(os.path.join(LR, kind + ".fq.gz"))
-    m = pkg.Mapper(gpu_ctx, names, seqs, preset=kind)
+    base, stem, preset = SETS[kind]
+    names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+    reads = read_fastq(os.path.join(base, stem + ".fq.gz"))
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset=preset, **OVERRIDES.get(kind, {}))
     try:
         res = m.map([r[1] for r in reads])
         got = []
@@ -27,6 +28,8 @@ def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
         # every DP of the HiFi fixture must have gone through the register-resident kernel
         if kind == "hifi":
             assert gpu_ctx.last_kernel_mask() & 1
+        if kind == "sr":  # 150 x 150, w = 150 boxes: the 16-lane kernel
+            assert gpu_ctx.last_kernel_mask() & 4
     finally:
         m.close()
 

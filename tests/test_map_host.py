@@ -10,7 +10,7 @@ import subprocess
 import pytest
 
 from conftest import ROOT
-from fixture_io import LR, golden_sam
+from fixture_io import LR, SETS, SR, golden_sam
 
 
 @pytest.fixture(scope="module")
@@ -20,17 +20,21 @@ def host_driver(tmp_path_factory):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-w", "-I", os.path.join(ROOT, "genome-on-diet_amd", "csrc"),
                            "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "emul", "map_host_main.cpp"),
                            "-x", "c", os.path.join(ROOT, "oracle", "gdo_ksw2.c"), "-o", exe])
-    for f in ("ref.fa", "hifi.fq", "ont.fq"):
-        with gzip.open(os.path.join(LR, f + ".gz"), "rb") as src, open(str(d / f), "wb") as dst:
-            shutil.copyfileobj(src, dst)
+    for sub, base, files in (("lr", LR, ("ref.fa", "hifi.fq", "ont.fq")), ("sr", SR, ("ref.fa", "sr.fq", "var.fq"))):
+        os.makedirs(str(d / sub))
+        for f in files:
+            with gzip.open(os.path.join(base, f + ".gz"), "rb") as src, open(str(d / sub / f), "wb") as dst:
+                shutil.copyfileobj(src, dst)
     return exe, str(d)
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont"])
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var"])
 def test_host_path_matches_golden_sam(host_driver, kind):
     exe, d = host_driver
-    cmd = open(os.path.join(LR, kind + ".cmd")).read().split()
-    out = subprocess.run([exe] + cmd + [os.path.join(d, "ref.fa"), os.path.join(d, kind + ".fq")], capture_output=True, text=True, check=True)
+    base, stem, _ = SETS[kind]
+    sub = os.path.join(d, os.path.basename(base))
+    cmd = open(os.path.join(base, stem + ".cmd")).read().split()
+    out = subprocess.run([exe] + cmd + [os.path.join(sub, "ref.fa"), os.path.join(sub, stem + ".fq")], capture_output=True, text=True, check=True)
     got = out.stdout.rstrip("\n").split("\n")
     want = golden_sam(kind)
     assert len(got) == len(want)
@@ -44,11 +48,12 @@ def test_host_path_matches_reference_binary_on_fresh_reads(host_driver, tmp_path
         pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
     exe, d = host_driver
     fq = str(tmp_path / "fresh.fq")
-    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "synth.py"), "reads", fq, "--ref", os.path.join(d, "ref.fa"), "--kind", "hifi", "--n", "20", "--seed", "77"])
+    ref_fa = os.path.join(d, "lr", "ref.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "synth.py"), "reads", fq, "--ref", ref_fa, "--kind", "hifi", "--n", "20", "--seed", "77"])
     cmd = open(os.path.join(LR, "hifi.cmd")).read().split()
-    want = subprocess.run([ref_bin, "-t", "4"] + cmd + [os.path.join(d, "ref.fa"), fq], capture_output=True, text=True, check=True).stdout
+    want = subprocess.run([ref_bin, "-t", "4"] + cmd + [ref_fa, fq], capture_output=True, text=True, check=True).stdout
     want = [l for l in want.rstrip("\n").split("\n") if not l.startswith("@")]
-    got = subprocess.run([exe] + cmd + [os.path.join(d, "ref.fa"), fq], capture_output=True, text=True, check=True).stdout.rstrip("\n").split("\n")
+    got = subprocess.run([exe] + cmd + [ref_fa, fq], capture_output=True, text=True, check=True).stdout.rstrip("\n").split("\n")
 
     def norm(line):
         # known, documented divergence (DESIGN.md "undefined behaviour in the reference"): for a reverse-strand record
@@ -60,3 +65,21 @@ def test_host_path_matches_reference_binary_on_fresh_reads(host_driver, tmp_path
         return "\t".join(f)
 
     assert [norm(x) for x in got] == [norm(x) for x in want]
+
+
+@pytest.mark.parametrize("extra", ["", "-N 5 -n 0.3,0.1 -s 40 --AF_max_loc 20", "-k 15 -w 10 -Z 110 -W 3 -i 0.5 -r 0.1,20,100 -n 2,1 -s 30 -N 3"])
+def test_sr_host_path_matches_reference_binary_on_fresh_reads(host_driver, tmp_path, extra):
+    """ShortReads variant on a fresh read set of mixed lengths (60-600 bp: both geometry branches, SR/map.c:796/809),
+    reads flush with the contig ends, Ns -- against a run of the reference binary"""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "gdiet_sr_avx")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    exe, d = host_driver
+    fq = str(tmp_path / "fresh.fq")
+    ref_fa = os.path.join(d, "sr", "ref.fa")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "synth_sr_var.py"), "41", "1500", fq, ref_fa])
+    cmd = (open(os.path.join(SR, "sr.cmd")).read() + " " + extra).split()
+    want = subprocess.run([ref_bin, "-t", "4"] + cmd + [ref_fa, fq], capture_output=True, text=True, check=True).stdout
+    want = [l for l in want.rstrip("\n").split("\n") if not l.startswith("@")]
+    got = subprocess.run([exe] + cmd + [ref_fa, fq], capture_output=True, text=True, check=True).stdout.rstrip("\n").split("\n")
+    assert got == want
