@@ -39,6 +39,7 @@ struct gdiet_ctx {
 	int map_lanes = 1;                 // software-pipeline depth of gdiet_hip_map_uploaded
 	std::vector<gdiet_ctx *> children; // the lanes (child contexts on the same device)
 	int seed_thread_kernel = 0;
+	int spread = 1;                    // the serial vote kernel runs one read per wavefront (GDIET_SPREAD=0: one per thread)
 	double stage_s[6] = {0, 0, 0, 0, 0, 0};
 	uint64_t last_cells = 0, last_alg_bytes = 0; // of the most recent DP launch
 };
@@ -107,6 +108,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 	{
 		const char *e = getenv("GDIET_SEED_KERNEL");
 		ctx->seed_thread_kernel = e && !strcmp(e, "thread");
+		const char *sp = getenv("GDIET_SPREAD");
+		if (sp) ctx->spread = atoi(sp) != 0;
 	}
 	*out = ctx;
 	return GDIET_OK;
@@ -178,7 +181,7 @@ static void gd_plan_one(int mode, bool wave_scoring_ok, int qlen, int tlen, int 
 	if (gd_wave_supported(qlen, tlen, w, 64)) {
 		if (gd_wave_supported(qlen, tlen, w, 16)) kind = GD_KIND_WAVE16, row_bytes = 16 * 16;
 		else kind = GD_KIND_WAVE64, row_bytes = 64 * 16;
-	}
+	} else if (gd_wave_supported(qlen, tlen, w, 128)) kind = GD_KIND_WAVE128; // row_bytes stays n_col_*16
 }
 
 extern "C" size_t gdiet_hip_ksw_workspace_bytes(int n, const int64_t *qoff, const int64_t *toff, const int32_t *w)
@@ -255,7 +258,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	const bool wave_scoring_ok = gd_wave_scoring_ok(K);
 	size_t bt = 0;
 	uint64_t cells_sum = 0, alg_sum = 0;
-	std::vector<int32_t> ids[3];
+	std::vector<int32_t> ids[4];
 	int max_cap = 0;
 	ctx->last_mask = 0;
 	for (int i = 0; i < n; ++i) {
@@ -284,10 +287,10 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		T.bt_off = (int64_t)bt;
 		bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
 		ids[T.kind].push_back(i);
-		ctx->last_mask |= T.kind == GD_KIND_GENERIC ? 2 : T.kind == GD_KIND_WAVE16 ? 4 : 1;
+		ctx->last_mask |= T.kind == GD_KIND_GENERIC ? 2 : T.kind == GD_KIND_WAVE16 ? 4 : T.kind == GD_KIND_WAVE128 ? 8 : 1;
 	}
 	// longest alignments first inside each class: the tail of the grid is then made of short jobs
-	for (int k = 0; k < 3; ++k)
+	for (int k = 0; k < 4; ++k)
 		std::stable_sort(ids[k].begin(), ids[k].end(), [&](int a, int b) {
 			const KswTask &A = ctx->h_tasks[a], &B = ctx->h_tasks[b];
 			if ((int64_t)A.qlen + A.tlen != (int64_t)B.qlen + B.tlen) return (int64_t)A.qlen + A.tlen > (int64_t)B.qlen + B.tlen;
@@ -313,8 +316,8 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		}
 	}
 	ctx->h_ids.clear();
-	size_t id_off[3];
-	for (int k = 0; k < 3; ++k) {
+	size_t id_off[4];
+	for (int k = 0; k < 4; ++k) {
 		id_off[k] = ctx->h_ids.size();
 		if (k == GD_KIND_WAVE16) ctx->h_ids.insert(ctx->h_ids.end(), quartets.begin(), quartets.end());
 		else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
@@ -341,6 +344,9 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	if (!ids[GD_KIND_WAVE16].empty())
 		gd_launch_wave16(d_tasks, d_ids + id_off[GD_KIND_WAVE16], (int)(quartets.size() / 4), d_qseq, d_tseq, d_bt,
 		                 d_status, d_score, K, stream);
+	if (!ids[GD_KIND_WAVE128].empty())
+		gd_launch_wave128(d_tasks, d_ids + id_off[GD_KIND_WAVE128], (int)ids[GD_KIND_WAVE128].size(), d_qseq, d_tseq, d_bt,
+		                  d_status, d_score, K, stream);
 	if (!ids[GD_KIND_GENERIC].empty()) {
 		const size_t lds = (size_t)max_cap * 7;
 		if (lds > 64 * 1024)
@@ -349,8 +355,9 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		                   d_tasks, d_ids + id_off[GD_KIND_GENERIC], d_qseq, d_tseq, d_bt, d_status, d_score, K, max_cap);
 	}
 	GD_HIP(hipEventRecord(ctx->ev[1], stream));
+	// one alignment per thread: measured 2x faster than one per wavefront (the 16-deep prefetch of 64 walks keeps far more loads in flight)
 	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_bt, d_status, d_score,
-	                   d_n_cigar, d_cigar);
+	                   d_n_cigar, d_cigar, 0);
 	GD_HIP(hipEventRecord(ctx->ev[2], stream));
 	GD_HIP(hipGetLastError());
 	return GDIET_OK;

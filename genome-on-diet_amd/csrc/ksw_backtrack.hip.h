@@ -7,7 +7,8 @@
 
 // position of cell (r, i) inside a backtrace row, for the two layouts the DP kernels write
 //   generic: the reference's own layout, column i - off[r] with off[r] = st0(r)/16*16 (SR/ksw2.h:142)
-//   wave:    lane-major ring: 16-cell block i>>4 lives in lane (i>>4) mod L (L = row_bytes/16); inside the
+//   wave:    lane-major ring: 16-cell block i>>4 lives in lane (i>>4) mod L (L = row_bytes/16; the two-blocks-per-lane
+//            kernel instead keeps the generic block position (i>>4) - off/16); inside the
 //            16 bytes of a lane cells are stored in the order the packed registers hold them
 //            (byte 4g+h holds cell 2g+(h&1)+8*(h>>1): cells k, k+1, k+8, k+9 of register pair g; see ksw_wave.hip.h)
 __device__ __forceinline__ size_t gd_bt_index(const KswTask &T, int r, int i, int off)
@@ -16,7 +17,9 @@ __device__ __forceinline__ size_t gd_bt_index(const KswTask &T, int r, int i, in
 	const int lanes = T.row_bytes >> 4;
 	const int c = i & 15;
 	const int g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
-	return (size_t)r * T.row_bytes + (size_t)(((i >> 4) & (lanes - 1)) << 4) + (g << 2) + h;
+	// 16/64-lane kernels: ring of `lanes` blocks; two-blocks-per-lane kernel: the reference's window-relative block position
+	const int bpos = T.kind == GD_KIND_WAVE128 ? (i >> 4) - (off >> 4) : ((i >> 4) & (lanes - 1));
+	return (size_t)r * T.row_bytes + (size_t)(bpos << 4) + (g << 2) + h;
 }
 
 __global__ __launch_bounds__(64) void ksw_exact_match_kernel(const KswTask *__restrict__ tasks, int n,
@@ -47,9 +50,15 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
                                                            const uint8_t *__restrict__ bt,
                                                            const int32_t *__restrict__ status,
                                                            int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
-                                                           uint32_t *__restrict__ cigar)
+                                                           uint32_t *__restrict__ cigar, int spread)
 {
-	const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+	// spread = 1: one alignment per WAVEFRONT (lane 0 walks, the other lanes idle).  Kept for experiments only: it measured 2x
+	// SLOWER than one walk per thread, whose 64 x 16 prefetched loads per wavefront hide the latency better.
+	int tid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (spread) {
+		if (threadIdx.x & 63) return;
+		tid >>= 6;
+	}
 	if (tid >= n) return;
 	const int st = status[tid];
 	if (st == GD_ST_EXACT) return;

@@ -9,6 +9,7 @@ enum : int32_t {
 	GD_KIND_GENERIC = 0, // LDS-resident literal kernel, any geometry that fits the LDS window
 	GD_KIND_WAVE64  = 1, // register-resident, one 64-lane wavefront per alignment (<= 64 16-cell blocks in flight)
 	GD_KIND_WAVE16  = 2, // register-resident, four alignments per wavefront (<= 16 blocks: short reads)
+	GD_KIND_WAVE128 = 3, // register-resident, two 16-cell blocks per lane (<= 128 blocks: ONT bands)
 };
 
 // One alignment of a batch.  Built on the host from the lengths, read by every kernel of the batch.

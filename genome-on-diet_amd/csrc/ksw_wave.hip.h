@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 
 	WaveLane L;
 	gdw_load_block(L, K, sub, 0, query, qlen, target, tlen);
+	bool any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0; // wave-uniform: does any lane hold a target N?
 	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
 	for (int r = 0; r <= rend; ++r) {
 		WaveRow W;
@@ -116,11 +117,14 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 			}
 			gdw_shift_query(L, pQ, L.blk == prev_st_, seam);
 		}
-		if (advanced && L.blk < W.st_) gdw_load_block(L, K, L.blk + LANES, r, query, qlen, target, tlen);
+		if (advanced) {
+			if (L.blk < W.st_) gdw_load_block(L, K, L.blk + LANES, r, query, qlen, target, tlen);
+			any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0;
+		}
 		// (3) scalar fix-ups and the score row
 		if (W.set_tr) gdw_reset_tr(L, K, W);
 		if (W.st0 != prev_st0 || W.up != prev_up || advanced) gdw_make_sel(L, W.st0, W.up);
-		gdw_update_scores(L, K);
+		gdw_update_scores(L, K, any_tn);
 		// (4) DP cells of the lanes inside the reference's 16-aligned window
 		if (L.blk <= W.en_) {
 			u32 out[4];
@@ -163,4 +167,115 @@ static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, in
 	WaveK K;
 	gdw_make_consts(C, K);
 	hipLaunchKernelGGL(ksw_extd2_wave_kernel<16>, dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
+}
+
+// ---- wide bands (ONT, w = 1300): 128 blocks in flight, TWO per lane ------------------------------------------------------
+// Block position p = blk mod 128 lives in lane p >> 1, sub-block p & 1, so a lane owns 32 consecutive cells.  The t-1
+// neighbour of sub-block 1 is sub-block 0 of the same lane (plain register copies taken before the row is updated), the
+// neighbour of sub-block 0 is sub-block 1 of the previous lane (DPP wave_ror:1).  Everything else is the 64-lane kernel
+// applied to each sub-block.
+__global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *__restrict__ tasks,
+                                                                const int32_t *__restrict__ task_ids, int n_tasks,
+                                                                const uint8_t *__restrict__ qseq,
+                                                                const uint8_t *__restrict__ tseq,
+                                                                uint8_t *__restrict__ bt, int32_t *__restrict__ status,
+                                                                int32_t *__restrict__ score_out, WaveK K)
+{
+	constexpr int NBLK = 128;
+	const int lane = threadIdx.x & 63;
+	const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+	if (slot >= n_tasks) return;
+	const int tid = __builtin_amdgcn_readfirstlane(task_ids[slot]);
+	if (__builtin_amdgcn_readfirstlane(status[tid]) != GD_ST_PENDING) return;
+	const KswTask *Tp = tasks + tid;
+	const int qlen = __builtin_amdgcn_readfirstlane(Tp->qlen), tlen = __builtin_amdgcn_readfirstlane(Tp->tlen);
+	int w = __builtin_amdgcn_readfirstlane(Tp->w);
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const uint8_t *query = qseq + Tp->qoff, *target = tseq + Tp->toff;
+	uint8_t *p = bt + Tp->bt_off;
+	const size_t row_bytes = (size_t)__builtin_amdgcn_readfirstlane(Tp->row_bytes);
+	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+
+	WaveLane L0, L1;
+	gdw_load_block(L0, K, 2 * lane, 0, query, qlen, target, tlen);
+	gdw_load_block(L1, K, 2 * lane + 1, 0, query, qlen, target, tlen);
+	bool any_tn = __builtin_amdgcn_ballot_w64((L0.tn | L1.tn) != 0) != 0;
+	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
+	for (int r = 0; r <= rend; ++r) {
+		WaveRow W;
+		W.r = r;
+		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+		const int advanced = W.st_ > prev_st_;
+		W.use_array = advanced;
+		W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
+		W.set_tr = (W.en0 | 15) >= r;
+		W.ukey = gdw_edge_key(K, r);
+		// (1) row r-1 values of the block below each sub-block, taken before anything is touched
+		const u32 pX0 = gdw_ror1<64>(L1.X[7]), pV0 = gdw_ror1<64>(L1.V[7]), pX20 = gdw_ror1<64>(L1.X2[7]), pQ0 = gdw_ror1<64>(L1.Qc[3]);
+		const u32 pX1 = L0.X[7], pV1 = L0.V[7], pX21 = L0.X2[7], pQ1 = L0.Qc[3];
+		// (2) query window advance; a sub-block that fell below the window takes over block +128
+		if (r > 0) {
+			const u32 seam = gdw_seam_byte(query, qlen, r - (prev_st_ << 4));
+			gdw_shift_query(L0, pQ0, L0.blk == prev_st_, seam);
+			gdw_shift_query(L1, pQ1, L1.blk == prev_st_, seam);
+		}
+		if (advanced) {
+			if (L0.blk < W.st_) gdw_load_block(L0, K, L0.blk + NBLK, r, query, qlen, target, tlen);
+			if (L1.blk < W.st_) gdw_load_block(L1, K, L1.blk + NBLK, r, query, qlen, target, tlen);
+			any_tn = __builtin_amdgcn_ballot_w64((L0.tn | L1.tn) != 0) != 0;
+		}
+		// (3) scalar fix-ups and the score row
+		if (W.set_tr) gdw_reset_tr(L0, K, W), gdw_reset_tr(L1, K, W);
+		if (W.st0 != prev_st0 || W.up != prev_up || advanced) gdw_make_sel(L0, W.st0, W.up), gdw_make_sel(L1, W.st0, W.up);
+		gdw_update_scores(L0, K, any_tn);
+		gdw_update_scores(L1, K, any_tn);
+		// (4) DP cells of the sub-blocks inside the reference's 16-aligned window
+		// backtrace row = the reference's own n_col_ blocks, block b at (b - st_) * 16 (SR/ksw2.h:142): 1.5x less arena than a
+		// 128-block ring, which is what bounds the number of 50 kbp alignments in flight
+		uint8_t *pr = p + (size_t)r * row_bytes;
+		if (L0.blk <= W.en_) {
+			u32 out[4];
+			gdw_compute(L0, K, W, pX0, pV0, pX20, out);
+			*reinterpret_cast<uint4 *>(pr + ((L0.blk - W.st_) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+		}
+		if (L1.blk <= W.en_) {
+			u32 out[4];
+			gdw_compute(L1, K, W, pX1, pV1, pX21, out);
+			*reinterpret_cast<uint4 *>(pr + ((L1.blk - W.st_) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+		}
+		// (5) score trackers
+		if (r == 0) L0.R = gdw_lo(L0.V[0]) - K.B1 - K.qe8, L1.R = gdw_lo(L1.V[0]) - K.B1 - K.qe8;
+		else L0.R += gdw_lo(L0.V[0]) - K.B1, L1.R += gdw_lo(L1.V[0]) - K.B1;
+		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 15) == 0) {
+			const int h0 = (int)gdw_ror1<64>((u32)gdw_track_handoff(L1)), h1 = gdw_track_handoff(L0);
+			if (L0.blk == W.en_) L0.R = h0 + gdw_lo(L0.U[0]);
+			if (L1.blk == W.en_) L1.R = h1 + gdw_lo(L1.U[0]);
+		}
+		if (W.en0 == tlen - 1) {
+			if (L0.blk == mlast) {
+				if (!have_f) Rf = gdw_track_to_slot(L0, sl);
+				else Rf += gdw_cell(L0.V, sl) - K.B1;
+			}
+			if (L1.blk == mlast) {
+				if (!have_f) Rf = gdw_track_to_slot(L1, sl);
+				else Rf += gdw_cell(L1.V, sl) - K.B1;
+			}
+			have_f = 1;
+		}
+		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
+	}
+	if (L0.blk == mlast || L1.blk == mlast) {
+		score_out[tid] = Rf >> 3;
+		status[tid] = GD_ST_DONE;
+	}
+}
+
+static inline void gd_launch_wave128(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
+                                     uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s)
+{
+	WaveK K;
+	gdw_make_consts(C, K);
+	hipLaunchKernelGGL(ksw_extd2_wave128_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K);
 }

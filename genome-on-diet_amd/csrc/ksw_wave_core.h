@@ -11,13 +11,15 @@
 // so "row r-1, cell t-1" is register k-1 (no instruction) except for k = 0, which takes one DPP rotate from the
 // previous lane plus one v_alignbit.  Arithmetic is packed 16-bit (v_pk_add/sub/max/min_i16): two cells per VALU
 // instruction.  Values are kept as KEYS  8*value + tie + bias:
-//     U,V: 8u+B1, 8v+B1      X: 8x+3+B1   Y: 8y+2+B1   X2: 8x2+1+B1   Y2: 8y2+B1      S: 8s+4+2*B1
-//     B1 = 8*(q+e-1)
-//   * a = X+V, b = Y+U, a2 = X2+V, b2 = Y2+U then all carry bias 2*B1 and tie codes 3,2,1,0 (S: 4), so ONE chain
-//     of four packed max gives both z (key & ~7) and the reference's direction d = 4 - (key & 7): the strict-'>'
-//     priority order z,a,b,a2,b2 of SR/ksw2_extd2_sse.c:235-242 is "largest value, then largest tie code".
+//     U,V: 8u+B1, 8v+B1      X: 8x+3+B1   Y: 8y+2+B1   X2: 8x2+1+B2   Y2: 8y2+B2      S: 8s+4+2*B1
+//     B1 = 8*(q+e-1), B2 = 8*(q2+e2-1)
+//   * a = X+V, b = Y+U carry bias 2*B1, a2 = X2+V, b2 = Y2+U carry B1+B2; with c2 = B1-B2 added to max(a2,b2) all
+//     five candidates carry bias 2*B1 and tie codes 4 (S),3,2,1,0, so a chain of packed max gives both z (key & ~7)
+//     and the reference's direction d = 4 - (key & 7): the strict-'>' priority order z,a,b,a2,b2 of
+//     SR/ksw2_extd2_sse.c:235-242 is "largest value, then largest tie code".
 //   * with B1 = 8(q+e-1) the no-continuation value x = -(q+e) is key -5 (y: -6) and every continuation value is
-//     >= 0, so the E/F continuation flags (:263,:266) are the sign bits of the stored X/Y registers.
+//     >= 0 (x2 = -(q2+e2): key -7, y2: -8 thanks to B2), so all four E/F continuation flags (:263-272) are the sign
+//     bits of the stored X/Y/X2/Y2 registers.
 // 8-bit wrap-around of the reference cannot occur for parameters accepted by gd_wave_supported() (all keys stay
 // far inside int16), so 16-bit arithmetic reproduces the int8 results exactly; the emulator test and the GPU
 // parity tests check that against the oracle.
@@ -88,11 +90,11 @@ GDW_HD int gdw_hi(u32 a) { return (int)(int16_t)(a >> 16); }
 // ---- uniform constants -------------------------------------------------------------------------------------
 struct WaveK {
 	int32_t B1;                // 8*(q+e-1)
-	u32 cx, cy, cx2, cy2;      // packed no-continuation / initial keys of X, Y, X2, Y2
+	u32 cx, cy, cx2, cy2;      // packed no-continuation / initial keys of X, Y, X2, Y2 (-5, -6, -7, -8)
+	u32 c2;                    // packed B1 - B2: lifts max(a2, b2) to the bias of the other candidates
 	u32 uv0;                   // packed initial key of U and V (value -(q+e))
 	u32 zmax;                  // packed 8*sc_mch + 2*B1
 	u32 te, te2;               // packed: tE = z8 - te (te = 8(q-1)); tE2 = z8 - te2 (te2 = B1 - 8*e2)
-	u32 w2x, w2y;              // packed cx2+1, cy2+1
 	u32 lut_lo, lut_hi;        // S-key bytes indexed by (T^Q)|TN: [match,mis,mis,mis] / [N,N,N,N]
 	u32 s0;                    // S-key byte of score 0, replicated (the reference's zero-filled s[])
 	int32_t key_open, key_e, key_ld, key_e2; // boundary keys of v1 / u[r]: -(q+e), -e, long_diff, -e2 (SR/ksw2_extd2_sse.c:158,162)
@@ -106,11 +108,12 @@ static inline bool gdw_make_consts(const KswConst &C, WaveK &K)
 	K.B1 = 8 * (qe - 1);
 	if (qe < 1) return false;
 	K.cx = gdw_pack2(8 * -qe + 3 + K.B1), K.cy = gdw_pack2(8 * -qe + 2 + K.B1);
-	K.cx2 = gdw_pack2(8 * -qe2 + 1 + K.B1), K.cy2 = gdw_pack2(8 * -qe2 + K.B1);
+	const int B2 = 8 * (qe2 - 1);
+	K.cx2 = gdw_pack2(8 * -qe2 + 1 + B2), K.cy2 = gdw_pack2(8 * -qe2 + B2);
+	K.c2 = gdw_pack2(K.B1 - B2);
 	K.uv0 = gdw_pack2(8 * -qe + K.B1);
 	K.zmax = gdw_pack2(8 * C.sc_mch + 2 * K.B1);
 	K.te = gdw_pack2(8 * (C.q - 1)), K.te2 = gdw_pack2(K.B1 - 8 * C.e2);
-	K.w2x = gdw_pack2(8 * -qe2 + 1 + K.B1 + 1), K.w2y = gdw_pack2(8 * -qe2 + K.B1 + 1);
 	const int km = 8 * C.sc_mch + 4 + 2 * K.B1, kx = 8 * C.sc_mis + 4 + 2 * K.B1, kn = 8 * C.sc_N + 4 + 2 * K.B1, k0 = 4 + 2 * K.B1;
 	if (km < 0 || km > 255 || kx < 0 || kx > 255 || kn < 0 || kn > 255 || k0 > 255) return false; // S keys must fit a byte
 	K.lut_lo = (u32)km | (u32)kx << 8 | (u32)kx << 16 | (u32)kx << 24;
@@ -137,6 +140,7 @@ struct WaveLane {
 	u32 Tb[4];   // target nt4 bytes of the block (0 beyond tlen)
 	u32 Qc[4];   // query nt4 bytes facing the cells on the current anti-diagonal: cell i <-> query[r - (tb+i)]
 	u32 SEL[4];  // v_perm selectors blending fresh scores into Sb (per byte: 4+i = take fresh, i = keep)
+	u32 tn;      // != 0 iff the block's target bytes contain an N (4): only then the score index needs its N fix-up
 	int32_t blk; // block index m held by the lane (m mod lanes == lane id)
 	int32_t R;   // 8*H(r, 16m): score tracker at cell 0 of the block
 };
@@ -163,6 +167,7 @@ GDW_HD void gdw_load_block(WaveLane &L, const WaveK &K, int m, int r, const uint
 		}
 		L.Tb[g] = tw, L.Qc[g] = qw, L.Sb[g] = K.s0, L.SEL[g] = 0x03020100u;
 	}
+	L.tn = (L.Tb[0] | L.Tb[1] | L.Tb[2] | L.Tb[3]) & 0x04040404u;
 	L.R = 0;
 }
 
@@ -205,17 +210,22 @@ GDW_HD void gdw_shift_query(WaveLane &L, u32 below, bool is_lowest, u32 seam)
 }
 
 // rewrite the persistent score bytes of this lane (every lane, active or not: the rewritten range may spill into
-// the first block above the computed window)
-GDW_HD void gdw_update_scores(WaveLane &L, const WaveK &K)
+// the first block above the computed window).  any_tn: some lane of the wavefront holds a target N (uniform).
+GDW_HD void gdw_update_scores(WaveLane &L, const WaveK &K, bool any_tn)
 {
+	// index of the AVX-512 score table (SR/ksw2_extd2_avx.c:183-209) folded into 3 bits: 0 match, 1-3 mismatch,
+	// 4-7 sc_N.  target ^ query is already right except when both are N (4 ^ 4 = 0): set bit 2 when the target is N
+	// and the query byte is not the reverse-complemented N (7 = 4 ^ 3, which the table scores as a mismatch vs N).
+	// Without a target N in the block the fix-up term is zero, so wavefronts without any (almost all) skip it.
+	if (any_tn) {
 #pragma unroll
-	for (int g = 0; g < 4; ++g) {
-		// index of the AVX-512 score table (SR/ksw2_extd2_avx.c:183-209) folded into 3 bits: 0 match, 1-3 mismatch,
-		// 4-7 sc_N.  target ^ query is already right except when both are N (4 ^ 4 = 0): set bit 2 when the target is N
-		// and the query byte is not the reverse-complemented N (7 = 4 ^ 3, which the table scores as a mismatch vs N).
-		const u32 x = (L.Tb[g] ^ L.Qc[g]) | (L.Tb[g] & ~(L.Qc[g] << 1) & 0x04040404u);
-		const u32 fresh = gdw_perm(K.lut_hi, K.lut_lo, x);
-		L.Sb[g] = gdw_perm(fresh, L.Sb[g], L.SEL[g]);
+		for (int g = 0; g < 4; ++g) {
+			const u32 x = (L.Tb[g] ^ L.Qc[g]) | (L.Tb[g] & ~(L.Qc[g] << 1) & 0x04040404u);
+			L.Sb[g] = gdw_perm(gdw_perm(K.lut_hi, K.lut_lo, x), L.Sb[g], L.SEL[g]);
+		}
+	} else {
+#pragma unroll
+		for (int g = 0; g < 4; ++g) L.Sb[g] = gdw_perm(gdw_perm(K.lut_hi, K.lut_lo, L.Tb[g] ^ L.Qc[g]), L.Sb[g], L.SEL[g]);
 	}
 }
 
@@ -237,7 +247,7 @@ GDW_HD void gdw_reset_tr(WaveLane &L, const WaveK &K, const WaveRow &W)
 
 // One anti-diagonal for one ACTIVE lane.  pX/pV/pX2: register 7 of X/V/X2 of the previous lane (row r-1 values).
 // bt: the lane's 16 backtrace bytes of this row (4 dwords; byte 4g+h = cell 2g+(h&1)+8*(h>>1)).
-// backtrace byte = (4 - d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6, n* = "no continuation" (inverse of :263-272)
+// backtrace byte = (4 - d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6, n* = "no continuation" (inverse of :263-272); bit 7 is undefined.
 GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u32 pV, u32 pX2, u32 bt[4])
 {
 	u32 inX = gdw_alignbit(L.X[7], pX, 16), inV = gdw_alignbit(L.V[7], pV, 16), inX2 = gdw_alignbit(L.X2[7], pX2, 16);
@@ -246,28 +256,30 @@ GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u
 		inV = (inV & 0xffff0000u) | ((u32)W.v1key & 0xffffu);
 		inX2 = (inX2 & 0xffff0000u) | (K.cx2 & 0xffffu);
 	}
-	u32 B[8];
+	u32 zk_hi = 0;
 #pragma unroll
 	for (int k = 7; k >= 0; --k) {
 		const u32 xin = k ? L.X[k - 1] : inX, vin = k ? L.V[k - 1] : inV, x2in = k ? L.X2[k - 1] : inX2;
 		const u32 sk = gdw_perm(L.Sb[2 + (k >> 2)], L.Sb[k >> 2], 0x0c000c00u | (u32)(k & 3) | (u32)(4 + (k & 3)) << 16);
 		const u32 a = pk_add(xin, vin), b = pk_add(L.Y[k], L.U[k]), a2 = pk_add(x2in, vin), b2 = pk_add(L.Y2[k], L.U[k]);
-		const u32 zk = pk_max(pk_max(pk_max(pk_max(sk, a), b), a2), b2);
-		const u32 dlow = zk & 0x00070007u;
+		const u32 zk = pk_max(pk_max(pk_max(sk, a), b), pk_add(pk_max(a2, b2), K.c2));
 		const u32 z8 = pk_min(zk & 0xfff8fff8u, K.zmax);
 		const u32 nU = pk_sub(z8, vin), nV = pk_sub(z8, L.U[k]);
 		const u32 tE = pk_sub(z8, K.te), tE2 = pk_sub(z8, K.te2);
-		const u32 nX = pk_max(pk_sub(a, tE), K.cx), nY = pk_max(pk_sub(b, tE), K.cy);
-		const u32 nX2 = pk_max(pk_sub(a2, tE2), K.cx2), nY2 = pk_max(pk_sub(b2, tE2), K.cy2);
-		const u32 wX2 = pk_sub(nX2, K.w2x), wY2 = pk_sub(nY2, K.w2y); // negative <=> no continuation
-		const u32 g1 = gdw_bfi(0x80008000u, nX, nY >> 1);
-		const u32 g2 = gdw_bfi(0x80008000u, wX2, wY2 >> 1);
-		const u32 g = gdw_bfi(0xc000c000u, g1, g2 >> 2);
-		B[k] = ((g >> 9) & 0x00780078u) | dlow;
-		L.U[k] = nU, L.V[k] = nV, L.X[k] = nX, L.Y[k] = nY, L.X2[k] = nX2, L.Y2[k] = nY2;
+		L.X[k] = pk_max(pk_sub(a, tE), K.cx), L.Y[k] = pk_max(pk_sub(b, tE), K.cy);
+		L.X2[k] = pk_max(pk_sub(a2, tE2), K.cx2), L.Y2[k] = pk_max(pk_sub(b2, tE2), K.cy2);
+		L.U[k] = nU, L.V[k] = nV;
+		if (k & 1) zk_hi = zk;
+		else {
+			// flags of register pairs k (cells k, k+8) and k+1 (cells k+1, k+9) together: the high byte of every 16-bit key
+			// carries its sign = "no continuation"; v_perm gathers them in backtrace byte order
+			const u32 hX = gdw_perm(L.X[k + 1], L.X[k], 0x07030501u), hY = gdw_perm(L.Y[k + 1], L.Y[k], 0x07030501u);
+			const u32 hX2 = gdw_perm(L.X2[k + 1], L.X2[k], 0x07030501u), hY2 = gdw_perm(L.Y2[k + 1], L.Y2[k], 0x07030501u);
+			const u32 f1 = gdw_bfi(0x80808080u, hX, hY >> 1), f2 = gdw_bfi(0x80808080u, hX2, hY2 >> 1);
+			const u32 f = gdw_bfi(0xc0c0c0c0u, f1, f2 >> 2);
+			bt[k >> 1] = gdw_bfi(0x78787878u, f >> 1, gdw_perm(zk_hi, zk, 0x06020400u));
+		}
 	}
-#pragma unroll
-	for (int g = 0; g < 4; ++g) bt[g] = B[2 * g] | (B[2 * g + 1] << 8);
 }
 
 // ---- score tracking ----------------------------------------------------------------------------------------

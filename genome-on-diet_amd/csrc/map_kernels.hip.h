@@ -71,9 +71,14 @@ struct MapVoteOut {
 __global__ __launch_bounds__(64) void map_vote_kernel(int n_reads, const int64_t *__restrict__ roff, GdIdxView I, MapDevOpt O,
                                                       const MapReadScratch *__restrict__ sc, const GdSeed *__restrict__ seed_arena,
                                                       const MapSeedOut *__restrict__ seeds, const int64_t *__restrict__ hit_off,
-                                                      GdLoc *__restrict__ hits /* 3 slices per read: for, rev, tmp */, MapVoteOut *__restrict__ out)
+                                                      GdLoc *__restrict__ hits /* 3 slices per read: for, rev, tmp */, MapVoteOut *__restrict__ out,
+                                                      int spread)
 {
-	const int rid = blockIdx.x * blockDim.x + threadIdx.x;
+	int rid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (spread) { // one read per wavefront, lane 0 only (see ksw_backtrack_kernel)
+		if (threadIdx.x & 63) return;
+		rid >>= 6;
+	}
 	if (rid >= n_reads) return;
 	MapVoteOut &o = out[rid];
 	o.n_cand = 0, o.pad = 0;

@@ -299,9 +299,9 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	if ((rc = gd_grow(ctx, ctx->m_hits, sizeof(GdLoc) * 3 * (size_t)(hoff[n] + 1)))) return rc;
 	GD_HIP(hipMemcpyAsync(ctx->m_hitoff.p, hoff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s));
 	// ---- S6, S7, V1, V3, G1a -----------------------------------------------------------------------------------------
-	hipLaunchKernelGGL(map_vote_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+	hipLaunchKernelGGL(map_vote_kernel, dim3(ctx->spread ? n : (n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 	                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
-	                   (MapVoteOut *)ctx->m_voteout.p);
+	                   (MapVoteOut *)ctx->m_voteout.p, ctx->spread);
 	std::vector<MapVoteOut> vo(n);
 	GD_HIP(hipMemcpyAsync(vo.data(), ctx->m_voteout.p, sizeof(MapVoteOut) * n, hipMemcpyDeviceToHost, s));
 	GD_HIP(hipStreamSynchronize(s));
@@ -449,7 +449,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		gdiet_ctx *c = nullptr;
 		int rc = gdiet_hip_init(&c, ctx->device);
 		if (rc) { ctx->err = "cannot create a pipeline lane"; return rc; }
-		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel;
+		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread;
 		ctx->children.push_back(c);
 	}
 	const int n_slices = std::min(n, lanes * 2);

@@ -54,10 +54,12 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 		}
 		// (3) per-row scalar fix-ups and the score row
 		const int remask = W.st0 != prev_st0 || W.up != prev_up || reloaded;
+		bool any_tn = false; // the device takes this from a wavefront ballot
+		for (int l = 0; l < LANES; ++l) any_tn |= L[l].tn != 0;
 		for (int l = 0; l < LANES; ++l) {
 			if (W.set_tr) gdw_reset_tr(L[l], K, W);
 			if (remask) gdw_make_sel(L[l], W.st0, W.up);
-			gdw_update_scores(L[l], K);
+			gdw_update_scores(L[l], K, any_tn);
 		}
 		// (4) the DP cells of the active lanes
 		for (int l = 0; l < LANES; ++l)
@@ -136,6 +138,7 @@ int main(int argc, char **argv)
 		int tlen, w;
 		double sub = 0.01, ins = 0.003, del = 0.003, nfrac = (it % 7 == 0) ? 0.02 : 0.0;
 		if (LANES == 16) tlen = 100 + g() % 120, w = 32 + g() % 130;
+		else if (LANES == 128) tlen = 1500 + g() % 3000, w = (it % 3 == 0) ? 1300 : 1010 + g() % 1000, sub = 0.03, ins = 0.02, del = 0.02; // ONT bands
 		else {
 			switch (it % 5) {
 			case 0: tlen = 150, w = 150; break;

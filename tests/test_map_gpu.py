@@ -28,6 +28,8 @@ def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
         # every DP of the HiFi fixture must have gone through the register-resident kernel
         if kind == "hifi":
             assert gpu_ctx.last_kernel_mask() & 1
+        if kind == "ont":  # w = 1300: the two-blocks-per-lane kernel
+            assert gpu_ctx.last_kernel_mask() & 8
         if kind == "sr":  # 150 x 150, w = 150 boxes: the 16-lane kernel
             assert gpu_ctx.last_kernel_mask() & 4
     finally:

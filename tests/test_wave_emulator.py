@@ -16,8 +16,8 @@ def emul(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("seed,lanes", [(1, 64), (2, 64), (3, 16)])
-def test_wave_core_matches_oracle(emul, seed, lanes):
-    out = subprocess.run([emul, str(seed), "400", str(lanes)], capture_output=True, text=True)
+@pytest.mark.parametrize("seed,lanes,n", [(1, 64, 400), (2, 64, 400), (3, 16, 400), (4, 128, 60)])
+def test_wave_core_matches_oracle(emul, seed, lanes, n):
+    out = subprocess.run([emul, str(seed), str(n), str(lanes)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
