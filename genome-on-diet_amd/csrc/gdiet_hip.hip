@@ -7,6 +7,10 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <atomic>
 
 #include "../../include/gdiet_hip.h"
 #include "ksw_common.h"
@@ -36,7 +40,9 @@ struct gdiet_ctx {
 	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack;
 	int host_threads = 8;
 	int lane_threads = 8;              // host threads this lane may use inside gd_map_range
+	void *pool = nullptr;              // GdPool (map_pipeline.hip.h), created on first use
 	int map_lanes = 1;                 // software-pipeline depth of gdiet_hip_map_uploaded
+	int slices_per_lane = 1;           // GDIET_SLICES_PER_LANE
 	std::vector<gdiet_ctx *> children; // the lanes (child contexts on the same device)
 	int seed_thread_kernel = 0;
 	int spread = 1;                    // the serial vote kernel runs one read per wavefront (GDIET_SPREAD=0: one per thread)
@@ -108,6 +114,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 	{
 		const char *e = getenv("GDIET_SEED_KERNEL");
 		ctx->seed_thread_kernel = e && !strcmp(e, "thread");
+		const char *sl = getenv("GDIET_SLICES_PER_LANE");
+		if (sl && atoi(sl) > 0) ctx->slices_per_lane = atoi(sl);
 		const char *sp = getenv("GDIET_SPREAD");
 		if (sp) ctx->spread = atoi(sp) != 0;
 	}
@@ -115,9 +123,12 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 	return GDIET_OK;
 }
 
+static void gd_pool_free(void *pool); // map_pipeline.hip.h
+
 extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 {
 	if (!ctx) return;
+	if (ctx->pool) gd_pool_free(ctx->pool), ctx->pool = nullptr;
 	for (gdiet_ctx *c : ctx->children) gdiet_hip_destroy(c);
 	ctx->children.clear();
 	(void)hipSetDevice(ctx->device);

@@ -22,15 +22,64 @@ struct gdiet_read_batch {
 	void *d_reads = nullptr, *d_roff = nullptr;
 };
 
-template <class F> static void gd_parallel_for(int n_threads, int n, F f)
-{
-	if (n_threads <= 1 || n < 2) { for (int i = 0; i < n; ++i) f(i); return; }
-	std::atomic<int> next(0);
+// Persistent host worker pool (one per context): the host stages of a batch are a few hundred microseconds of work per
+// thread, so creating the threads per call (tens of microseconds EACH, serialised) used to cost more than the work.
+struct GdPool {
 	std::vector<std::thread> th;
-	for (int t = 0; t < n_threads; ++t)
-		th.emplace_back([&]() { for (;;) { const int i = next.fetch_add(16); if (i >= n) break; for (int j = i; j < std::min(n, i + 16); ++j) f(j); } });
-	for (auto &t : th) t.join();
+	std::mutex mu;
+	std::condition_variable cv_go, cv_done;
+	std::function<void(int)> job;
+	std::atomic<int> next{0};
+	int n = 0, gen = 0, active = 0, width = 0;
+	bool stop = false;
+	void worker(int id)
+	{
+		int seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv_go.wait(lk, [&] { return stop || gen != seen; });
+				if (stop) return;
+				seen = gen;
+				if (id >= width) { if (--active == 0) cv_done.notify_one(); continue; }
+			}
+			for (;;) { const int i = next.fetch_add(16); if (i >= n) break; for (int j = i; j < std::min(n, i + 16); ++j) job(j); }
+			std::unique_lock<std::mutex> lk(mu);
+			if (--active == 0) cv_done.notify_one();
+		}
+	}
+	void ensure(int n_threads) { while ((int)th.size() < n_threads) { const int id = (int)th.size(); th.emplace_back([this, id] { worker(id); }); } }
+	template <class F> void run(int n_threads, int n_items, F f)
+	{
+		if (n_threads <= 1 || n_items < 32) { for (int i = 0; i < n_items; ++i) f(i); return; }
+		n_threads = std::min(n_threads, (n_items + 15) / 16);
+		ensure(n_threads - 1); // the caller works too
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			job = f, n = n_items, next = 0, width = n_threads - 1, active = (int)th.size(), ++gen;
+		}
+		cv_go.notify_all();
+		for (;;) { const int i = next.fetch_add(16); if (i >= n_items) break; for (int j = i; j < std::min(n_items, i + 16); ++j) f(j); }
+		std::unique_lock<std::mutex> lk(mu);
+		cv_done.wait(lk, [&] { return active == 0; });
+	}
+	~GdPool()
+	{
+		{ std::unique_lock<std::mutex> lk(mu); stop = true; }
+		cv_go.notify_all();
+		for (auto &t : th) t.join();
+	}
+};
+
+static void gd_pool_free(void *pool) { delete (GdPool *)pool; }
+
+static GdPool *gd_pool(gdiet_ctx *ctx)
+{
+	if (!ctx->pool) ctx->pool = new GdPool();
+	return (GdPool *)ctx->pool;
 }
+
+template <class F> static void gd_parallel_for(gdiet_ctx *ctx, int n_threads, int n, F f) { gd_pool(ctx)->run(n_threads, n, f); }
 
 static double gd_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -172,7 +221,7 @@ extern "C" int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **out, in
 	b->roff.assign(n + 1, 0);
 	for (int i = 0; i < n; ++i) b->roff[i + 1] = b->roff[i] + (lens[i] > 0 ? lens[i] : 0);
 	b->enc.resize((size_t)b->roff[n] + 8);
-	gd_parallel_for(ctx->host_threads, n, [&](int i) {
+	gd_parallel_for(ctx, ctx->host_threads, n, [&](int i) {
 		uint8_t *d = b->enc.data() + b->roff[i];
 		for (int j = 0; j < lens[i]; ++j) d[j] = gd_nt4((unsigned char)seqs[i][j]);
 	});
@@ -309,7 +358,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
 	const GdRefView R = ix->h.ref();
 	std::vector<std::vector<GdCand>> cand(n);
-	gd_parallel_for(ctx->lane_threads, n, [&](int i) {
+	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
 		const unsigned nc = vo[i].n_cand;
 		if (!nc) return;
 		cand[i].resize(nc);
@@ -390,7 +439,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	}
 	ctx->stage_s[3] += gd_now() - t0, t0 = gd_now();
 	// ---- P1-P3 (host threads) ---------------------------------------------------------------------------------------------
-	gd_parallel_for(ctx->lane_threads, n, [&](int i) {
+	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
 		n_regs[i] = 0, regs[i] = nullptr;
 		const size_t nc = cand[i].size();
 		if (!nc) return;
@@ -452,7 +501,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread;
 		ctx->children.push_back(c);
 	}
-	const int n_slices = std::min(n, lanes * 2);
+	const int n_slices = std::min(n, lanes * ctx->slices_per_lane);
 	std::atomic<int> next(0);
 	std::vector<int> rcs(lanes, 0);
 	std::vector<std::thread> th;
