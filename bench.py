@@ -154,12 +154,14 @@ def cpu_baseline_port(reads_enc, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="reads per step per GPU")
     ap.add_argument("--ref-mbp", type=float, default=float(os.environ.get("GDIET_BENCH_REF_MBP", "3088")),
                     help="size of the synthetic reference in Mbp (default: GRCh38-sized)")
     ap.add_argument("--lanes", type=int, default=1, help="software-pipeline depth inside a step (gdiet_hip_set_map_lanes)")
+    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="batches in flight (gdiet_hip_map_submit/_wait): 2 overlaps the seeding/voting/host stages of step i+1 with the DP kernel of step i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -193,13 +195,33 @@ def main():
     clock = pkg.JobClock(dist if world > 1 else None, dev, lambda: torch.cuda.synchronize(dev))
     res = None
     mapper.set_lanes(args.lanes)
-    for _ in range(args.warmup):
-        res = mapper.map_uploaded(batch)
+    if args.inflight > 1:
+        mapper.set_inflight(args.inflight)
+    def run_steps(k, stages=None):
+        """k passes over the batch; with --inflight 2 step i+1 is submitted before step i is waited for"""
+        last, open_t = None, []
+        for _ in range(k):
+            if args.inflight == 1:
+                last = mapper.map_uploaded(batch)  # returns when every read of the batch has its records on the host
+            else:
+                open_t.append(mapper.submit(batch))
+                if len(open_t) == args.inflight:
+                    last = mapper.wait(open_t.pop(0))
+                    if stages is not None:
+                        stages.append(mapper.stage_seconds())
+            if args.inflight == 1 and stages is not None:
+                stages.append(mapper.stage_seconds())
+        while open_t:
+            last = mapper.wait(open_t.pop(0))
+            if stages is not None:
+                stages.append(mapper.stage_seconds())
+        return last
+
+    run_steps(args.inflight)  # set-up, like the index build: each lane allocates its device scratch on its first batch
+    res = run_steps(args.warmup)
     clock.start()  # synchronize + barrier + synchronize
     kern, stages = [], []
-    for _ in range(args.steps):
-        res = mapper.map_uploaded(batch)  # returns when every read of the batch has its records on the host
-        stages.append(mapper.stage_seconds())
+    res = run_steps(args.steps, stages)  # every record of all K batches is on the host when this returns
     elapsed = clock.stop()  # synchronize + barrier
     # roofline of the dominant kernel: one extra, un-pipelined pass (outside the timed region) so that the DP kernel runs alone
     # between its HIP events, as it does under rocprofv3 --kernel-trace
@@ -245,7 +267,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "p50_read_latency_ms": 1e3 * elapsed / args.steps,
+            "p50_read_latency_ms": 1e3 * elapsed / args.steps * args.inflight,
             "config": {"workload": "BASELINE configs[3]: GDiet-LongReads -ax map-hifi k19 w19 -Z 10 -W 2 -i 0.2 -r 1000 ..., synthetic ~15 kbp HiFi reads vs "
                                    "synthetic reference of %.0f Mbp in 24 contigs (GRCh38-sized = 3088)" % args.ref_mbp,
                        "reads_per_step_per_gpu": len(reads), "bases_per_step_per_gpu": int(read_lens.sum()), "mapped_fraction": float(mapped.mean()),
@@ -253,7 +275,8 @@ def main():
                        "setup_s": {"reference": round(t_ref, 1), "index_build_upload": round(t_index, 1)},
                        "stage_s_per_step": {"seed_kernel": st[0], "vote_kernel": st[1], "host_geometry": st[2], "gather_dp_backtrack": st[3],
                                             "host_postprocess": st[4], "other": st[5]},
-                       "p50_read_latency_note": "every read of a batch completes with its batch (batch = ms_per_step)",
+                       "p50_read_latency_note": "every read of a batch completes with its batch; with 2 batches in flight a batch takes ~2 x ms_per_step from submit to wait",
+                       "batches_in_flight": args.inflight,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": cores, "pipeline_lanes": args.lanes},
             "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave_kernel<64>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(alg), "dp_cells_per_launch": int(cells), "gcups": cells / (dp * 1e-3) / 1e9, "kernel_ms": dp,

@@ -41,6 +41,13 @@ struct gdiet_ctx {
 	int host_threads = 8;
 	int lane_threads = 8;              // host threads this lane may use inside gd_map_range
 	void *pool = nullptr;              // GdPool (map_pipeline.hip.h), created on first use
+	// batches in flight (gdiet_hip_map_submit / _wait): up to GD_MAX_INFLIGHT lane contexts (own stream and scratch) that share THIS
+	// context's backtrace arena, one DP stage at a time
+	gdiet_ctx *parent = nullptr;       // set in an async lane
+	std::mutex dp_mu;                  // serialises the DP stage (and with it the use of the arena) between the lanes
+	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
+	bool async_busy[4] = {false, false, false, false};
+	int async_next = 0, async_depth = 2;
 	int map_lanes = 1;                 // software-pipeline depth of gdiet_hip_map_uploaded
 	int slices_per_lane = 1;           // GDIET_SLICES_PER_LANE
 	std::vector<gdiet_ctx *> children; // the lanes (child contexts on the same device)
@@ -131,6 +138,8 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	if (ctx->pool) gd_pool_free(ctx->pool), ctx->pool = nullptr;
 	for (gdiet_ctx *c : ctx->children) gdiet_hip_destroy(c);
 	ctx->children.clear();
+	for (int i = 0; i < 4; ++i)
+		if (ctx->async_lane[i]) gdiet_hip_destroy(ctx->async_lane[i]), ctx->async_lane[i] = nullptr;
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar,
@@ -334,7 +343,8 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
 	}
 	ctx->last_cells = cells_sum, ctx->last_alg_bytes = alg_sum;
-	if ((rc = gd_grow(ctx, ctx->arena, bt))) return rc;
+	DevBuf &arena = ctx->parent ? ctx->parent->arena : ctx->arena; // an async lane works in its parent's arena (under parent->dp_mu)
+	if ((rc = gd_grow(ctx, arena, bt))) return rc;
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * ctx->h_ids.size()))) return rc;
 	if ((rc = gd_grow(ctx, ctx->status, sizeof(int32_t) * n))) return rc;
@@ -344,7 +354,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	const KswTask *d_tasks = (const KswTask *)ctx->tasks.p;
 	const int32_t *d_ids = (const int32_t *)ctx->ids.p;
 	int32_t *d_status = (int32_t *)ctx->status.p;
-	uint8_t *d_bt = (uint8_t *)ctx->arena.p;
+	uint8_t *d_bt = (uint8_t *)arena.p;
 
 	GD_HIP(hipEventRecord(ctx->ev[0], stream));
 	hipLaunchKernelGGL(ksw_exact_match_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_qseq, d_tseq,

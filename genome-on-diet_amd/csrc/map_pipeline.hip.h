@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <mutex>
 #include "map_host.h"
 #include "map_index.h"
 #include "map_kernels.hip.h"
@@ -281,6 +282,22 @@ static void gd_opt_from_c(const gdiet_mapopt_t *o, const gdiet_index *ix, GdMapO
 	O.af_max_loc = o->AF_max_loc;
 }
 
+#define GD_MAX_INFLIGHT 4
+static void gd_drop_async_lanes(gdiet_ctx *ctx)
+{
+	for (int i = 0; i < GD_MAX_INFLIGHT; ++i)
+		if (ctx->async_lane[i] && !ctx->async_busy[i]) gdiet_hip_destroy(ctx->async_lane[i]), ctx->async_lane[i] = nullptr;
+}
+
+static int gd_check_opt(gdiet_ctx *ctx, const GdMapOpt &O)
+{
+	if (O.flag & GD_F_SR) {
+		if (O.af_max_loc < 1 || O.af_max_loc > GDM_MAX_VT) { ctx->err = "AF_max_loc must be in [1," + std::to_string(GDM_MAX_VT) + "]"; return GDIET_E_PARAM; }
+	} else if (O.vt_nb_loc + 2 > GDM_MAX_VT) { ctx->err = "vt_nb_loc too large"; return GDIET_E_PARAM; }
+	if (O.mid_occ <= 0) { ctx->err = "mid_occ must be set (mm_mapopt_update)"; return GDIET_E_PARAM; }
+	return GDIET_OK;
+}
+
 // a contiguous slice of a resident read batch
 struct GdBatchView {
 	int n;
@@ -400,6 +417,13 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	std::vector<int32_t> h_score(nb), h_ncig(nb);
 	std::vector<uint32_t> h_cig;
 	std::vector<int64_t> poff(1, 0);
+	// an async lane shares its parent's backtrace arena (two whole-batch arenas do not fit in HBM, and concurrent DP kernels of
+	// smaller batches measured slower): one DP stage (gather .. CIGARs on the host) at a time
+	std::unique_lock<std::mutex> dp_lock;
+	if (ctx->parent) {
+		dp_lock = std::unique_lock<std::mutex>(ctx->parent->dp_mu);
+		ctx->stage_s[5] += gd_now() - t0, t0 = gd_now(); // waiting for the other batch's DP is not this batch's stage time
+	}
 	if (nb > 0) {
 		if ((rc = gd_grow(ctx, ctx->m_boxes, sizeof(MapBox) * nb))) return rc;
 		if ((rc = gd_grow(ctx, ctx->m_q, (size_t)qoff[nb] + 64))) return rc;
@@ -437,6 +461,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			GD_HIP(hipStreamSynchronize(s));
 		}
 	}
+	if (dp_lock.owns_lock()) dp_lock.unlock();
 	ctx->stage_s[3] += gd_now() - t0, t0 = gd_now();
 	// ---- P1-P3 (host threads) ---------------------------------------------------------------------------------------------
 	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
@@ -481,12 +506,15 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	if (n == 0) return GDIET_OK;
 	GdMapOpt O;
 	gd_opt_from_c(copt, ix, O);
-	if (O.flag & GD_F_SR) {
-		if (O.af_max_loc < 1 || O.af_max_loc > GDM_MAX_VT) { ctx->err = "AF_max_loc must be in [1," + std::to_string(GDM_MAX_VT) + "]"; return GDIET_E_PARAM; }
-	} else if (O.vt_nb_loc + 2 > GDM_MAX_VT) { ctx->err = "vt_nb_loc too large"; return GDIET_E_PARAM; }
-	if (O.mid_occ <= 0) { ctx->err = "mid_occ must be set (mm_mapopt_update)"; return GDIET_E_PARAM; }
+	{ const int rc = gd_check_opt(ctx, O); if (rc) return rc; }
+	for (int i = 0; i < 4; ++i)
+		if (ctx->async_busy[i]) { ctx->err = "batches submitted with gdiet_hip_map_submit are still in flight"; return GDIET_E_PARAM; }
+
 	const int lanes = std::max(1, std::min(ctx->map_lanes, (n + 255) / 256));
 	if (lanes == 1) {
+		// the backtrace arena of a whole batch is ~40 % of HBM: lanes left over from a pipelined call must give theirs back first
+		for (gdiet_ctx *c : ctx->children) gdiet_hip_destroy(c);
+		ctx->children.clear();
 		ctx->lane_threads = ctx->host_threads;
 		GdBatchView V = {n, B->roff.data(), B->enc.data(), (const uint8_t *)B->d_reads, (const int64_t *)B->d_roff};
 		return gd_map_range(ctx, ix, O, V, n_regs, regs);
@@ -494,6 +522,11 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	// Software pipeline over slices of the batch: every lane (a child context with its own stream, workspace and host threads)
 	// runs the whole chain for one slice at a time, so the latency-bound kernels (seed, vote, backtrack), the transfers and the
 	// host stages of one slice overlap with the DP kernel of the others.  No result depends on the slicing.
+	if (ctx->arena.p) { // ... and the parent's whole-batch arena is not needed while the lanes hold their own
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipFree(ctx->arena.p);
+		ctx->arena.p = nullptr, ctx->arena.cap = 0;
+	}
 	while ((int)ctx->children.size() < lanes) {
 		gdiet_ctx *c = nullptr;
 		int rc = gdiet_hip_init(&c, ctx->device);
@@ -530,6 +563,73 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		ctx->last_mask |= c->last_mask;
 	}
 	return GDIET_OK;
+}
+
+// ---- several batches in flight ---------------------------------------------------------------------------------------------------
+// gdiet_hip_map_submit starts the whole path for one resident batch on a lane of its own (stream, scratch) and returns;
+// gdiet_hip_map_wait joins it.  The seeding / voting kernels and the host stages of one batch then run while the DP kernel of
+// another owns the GPU; the DP stages themselves take turns in the shared backtrace arena.  The reference overlaps its mini-batches the same way (kt_pipeline, LR/map.c:2094-2170).  Results do not depend on it.
+struct gdiet_map_ticket {
+	std::thread th;
+	int rc = 0, lane = 0;
+	GdMapOpt O;
+};
+
+extern "C" int gdiet_hip_set_inflight(gdiet_ctx *ctx, int n)
+{
+	if (!ctx || n < 1 || n > GD_MAX_INFLIGHT) return GDIET_E_PARAM;
+	for (int i = 0; i < GD_MAX_INFLIGHT; ++i) if (ctx->async_busy[i]) { ctx->err = "batches are in flight"; return GDIET_E_PARAM; }
+	gd_drop_async_lanes(ctx);
+	ctx->async_depth = n, ctx->async_next = 0;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *ix, const gdiet_mapopt_t *copt, gdiet_read_batch *B, int32_t *n_regs,
+                                    gdiet_reg_t **regs, gdiet_map_ticket **out)
+{
+	if (!ctx || !ix || !copt || !B || !n_regs || !regs || !out) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	gdiet_map_ticket *t = new gdiet_map_ticket();
+	gd_opt_from_c(copt, ix, t->O);
+	int rc = gd_check_opt(ctx, t->O);
+	if (rc) { delete t; return rc; }
+	const int l = ctx->async_next % ctx->async_depth;
+	if (ctx->async_busy[l]) { delete t; ctx->err = "too many batches in flight: wait for the oldest ticket first"; return GDIET_E_PARAM; }
+	// the backtrace arenas are the big consumers of HBM: the intra-batch lanes give theirs back
+	for (gdiet_ctx *c : ctx->children) gdiet_hip_destroy(c);
+	ctx->children.clear();
+	if (!ctx->async_lane[l]) {
+		gdiet_ctx *c = nullptr;
+		rc = gdiet_hip_init(&c, ctx->device);
+		if (rc) { delete t; ctx->err = "cannot create an async lane"; return rc; }
+		c->parent = ctx;
+		ctx->async_lane[l] = c;
+	}
+	gdiet_ctx *c = ctx->async_lane[l];
+	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread;
+	c->lane_threads = c->host_threads = std::max(1, ctx->host_threads / ctx->async_depth);
+	ctx->async_busy[l] = true, ctx->async_next++;
+	t->lane = l;
+	t->th = std::thread([=]() {
+		GdBatchView V = {B->n, B->roff.data(), B->enc.data(), (const uint8_t *)B->d_reads, (const int64_t *)B->d_roff};
+		t->rc = B->n ? gd_map_range(c, ix, t->O, V, n_regs, regs) : GDIET_OK;
+	});
+	*out = t;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_map_wait(gdiet_ctx *ctx, gdiet_map_ticket *t)
+{
+	if (!ctx || !t) return GDIET_E_PARAM;
+	if (t->th.joinable()) t->th.join();
+	gdiet_ctx *c = ctx->async_lane[t->lane];
+	const int rc = t->rc;
+	if (rc) ctx->err = c->err;
+	for (int i = 0; i < 6; ++i) ctx->stage_s[i] = c->stage_s[i];
+	ctx->last_mask = c->last_mask, ctx->last_cells = c->last_cells, ctx->last_alg_bytes = c->last_alg_bytes;
+	ctx->async_busy[t->lane] = false;
+	delete t;
+	return rc;
 }
 
 extern "C" int gdiet_hip_map_batch(gdiet_ctx *ctx, const gdiet_index *ix, const gdiet_mapopt_t *opt, int n, const char *const *seqs,

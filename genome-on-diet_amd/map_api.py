@@ -70,6 +70,9 @@ def _bind(lib):
     lib.gdiet_hip_free_regs.restype = None
     lib.gdiet_hip_batch_upload.argtypes = [vp, C.POINTER(vp), C.c_int, cpp, i32p]
     lib.gdiet_hip_map_uploaded.argtypes = [vp, vp, C.POINTER(MapOpt), vp, i32p, C.POINTER(C.POINTER(Reg))]
+    lib.gdiet_hip_map_submit.argtypes = [vp, vp, C.POINTER(MapOpt), vp, i32p, C.POINTER(C.POINTER(Reg)), C.POINTER(vp)]
+    lib.gdiet_hip_map_wait.argtypes = [vp, vp]
+    lib.gdiet_hip_set_inflight.argtypes = [vp, C.c_int]
     lib.gdiet_hip_batch_destroy.argtypes = [vp, vp]
     lib.gdiet_hip_batch_destroy.restype = None
     lib.gdiet_hip_map_stage_seconds.argtypes = [vp, C.POINTER(C.c_double)]
@@ -212,6 +215,23 @@ class Mapper:
         n_regs = (C.c_int32 * n)()
         regs = (C.POINTER(Reg) * n)()
         self.ctx._check(self.lib.gdiet_hip_map_uploaded(self.ctx._h, self._idx, C.byref(self.opt), h, n_regs, regs))
+        return MapResult(self.lib, n, n_regs, regs)
+
+    def set_inflight(self, n):
+        self.ctx._check(self.lib.gdiet_hip_set_inflight(self.ctx._h, n))
+
+    def submit(self, batch):
+        """start mapping a resident batch (gdiet_hip_map_submit); returns a ticket for wait().  At most two may be open."""
+        h, n = batch
+        n_regs = (C.c_int32 * n)()
+        regs = (C.POINTER(Reg) * n)()
+        t = C.c_void_p()
+        self.ctx._check(self.lib.gdiet_hip_map_submit(self.ctx._h, self._idx, C.byref(self.opt), h, n_regs, regs, C.byref(t)))
+        return (t, n, n_regs, regs)
+
+    def wait(self, ticket):
+        t, n, n_regs, regs = ticket
+        self.ctx._check(self.lib.gdiet_hip_map_wait(self.ctx._h, t))
         return MapResult(self.lib, n, n_regs, regs)
 
     def set_lanes(self, n):

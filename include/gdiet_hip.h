@@ -196,6 +196,17 @@ int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **batch, int n_reads
 int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, gdiet_read_batch *batch,
                            int32_t *n_regs, gdiet_reg_t **regs);
 void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *batch);
+/* Several batches in flight: _submit starts the whole path for a resident batch on a lane of its own (stream, scratch) and
+ * returns a ticket, _wait joins it (results in the n_regs / regs arrays given to _submit).  Up to
+ * gdiet_hip_set_inflight() tickets (default 2, at most 4) may be open; wait for them in submission order.  The latency-bound
+ * stages of one batch overlap the DP kernel of another, exactly as the reference's kt_pipeline overlaps the steps of consecutive
+ * mini-batches (LR/map.c:2094-2170); results are those of gdiet_hip_map_uploaded.  The lanes share one backtrace arena (~34 MB
+ * per 15 kbp alignment: two whole-batch arenas would not fit in HBM), so their DP stages take turns. */
+typedef struct gdiet_map_ticket gdiet_map_ticket;
+int gdiet_hip_set_inflight(gdiet_ctx *ctx, int n);
+int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, gdiet_read_batch *batch,
+                         int32_t *n_regs, gdiet_reg_t **regs, gdiet_map_ticket **ticket);
+int gdiet_hip_map_wait(gdiet_ctx *ctx, gdiet_map_ticket *ticket);
 /* seconds spent in the stages of the most recent map call: [0] seed kernel, [1] vote kernel, [2] host geometry,
  * [3] gather + DP + backtrack kernels, [4] host post-processing, [5] transfers/other */
 int gdiet_hip_map_stage_seconds(const gdiet_ctx *ctx, double out[6]);

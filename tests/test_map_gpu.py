@@ -89,3 +89,31 @@ def test_index_import_route_gives_identical_sam(gpu_ctx, pkg):
             m2.close()
     finally:
         m.close()
+
+
+def test_two_batches_in_flight_give_the_same_records(gpu_ctx, pkg):
+    """gdiet_hip_map_submit / _wait: two resident batches in flight (different read sets), several rounds; every record equals
+    what the synchronous call returns"""
+    names, seqs = read_fasta(os.path.join(LR, "ref.fa.gz"))
+    reads = read_fastq(os.path.join(LR, "hifi.fq.gz"))
+    ra, rb = reads[: len(reads) // 2], reads[len(reads) // 2:]
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset="hifi")
+    try:
+        ba, bb = m.upload([r[1] for r in ra]), m.upload([r[1] for r in rb])
+
+        def sam(res, rs):
+            return [m.sam(res, i, rs[i][0], rs[i][1], rs[i][2]) for i in range(len(rs))]
+
+        want_a, want_b = sam(m.map_uploaded(ba), ra), sam(m.map_uploaded(bb), rb)
+        for _ in range(3):
+            ta = m.submit(ba)
+            tb = m.submit(bb)
+            with pytest.raises(pkg.GdietError):  # a third ticket must be refused, not queued silently
+                m.submit(ba)
+            assert sam(m.wait(ta), ra) == want_a
+            assert sam(m.wait(tb), rb) == want_b
+        assert sam(m.map_uploaded(ba), ra) == want_a  # the synchronous path still works afterwards
+        m.free_batch(ba)
+        m.free_batch(bb)
+    finally:
+        m.close()
