@@ -52,6 +52,7 @@ struct gdiet_ctx {
 	int slices_per_lane = 1;           // GDIET_SLICES_PER_LANE
 	std::vector<gdiet_ctx *> children; // the lanes (child contexts on the same device)
 	int seed_thread_kernel = 0;
+	int bt_wave = 1;                   // GDIET_BT_WAVE=0: always the one-walk-per-thread backtrack kernel
 	int spread = 1;                    // the serial vote kernel runs one read per wavefront (GDIET_SPREAD=0: one per thread)
 	double stage_s[6] = {0, 0, 0, 0, 0, 0};
 	uint64_t last_cells = 0, last_alg_bytes = 0; // of the most recent DP launch
@@ -123,6 +124,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		ctx->seed_thread_kernel = e && !strcmp(e, "thread");
 		const char *sl = getenv("GDIET_SLICES_PER_LANE");
 		if (sl && atoi(sl) > 0) ctx->slices_per_lane = atoi(sl);
+		const char *bw = getenv("GDIET_BT_WAVE");
+		if (bw) ctx->bt_wave = atoi(bw) != 0;
 		const char *sp = getenv("GDIET_SPREAD");
 		if (sp) ctx->spread = atoi(sp) != 0;
 	}
@@ -376,9 +379,12 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		                   d_tasks, d_ids + id_off[GD_KIND_GENERIC], d_qseq, d_tseq, d_bt, d_status, d_score, K, max_cap);
 	}
 	GD_HIP(hipEventRecord(ctx->ev[1], stream));
-	// one alignment per thread: measured 2x faster than one per wavefront (the 16-deep prefetch of 64 walks keeps far more loads in flight)
-	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_bt, d_status, d_score,
-	                   d_n_cigar, d_cigar, 0);
+	// long walks: one wavefront each (64-cell diagonal prefetch + scalar walk); short reads: one walk per thread
+	if (ctx->bt_wave && cells_sum / (uint64_t)n > 200000)
+		hipLaunchKernelGGL(ksw_backtrack_wave_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, d_tasks, n, d_bt, d_status, d_score, d_n_cigar, d_cigar);
+	else
+		hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_bt, d_status, d_score,
+		                   d_n_cigar, d_cigar, 0);
 	GD_HIP(hipEventRecord(ctx->ev[2], stream));
 	GD_HIP(hipGetLastError());
 	return GDIET_OK;

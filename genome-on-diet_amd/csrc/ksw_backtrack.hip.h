@@ -140,3 +140,89 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 			cg[k] = cg[nc - 1 - k], cg[nc - 1 - k] = t0;
 		}
 }
+
+// K2 for long alignments: one WAVEFRONT per walk.  All 64 lanes fetch the next 64 cells of the current diagonal at once (one
+// round trip instead of one per cell), then the walk itself -- wave-uniform by construction -- runs as scalar code that pulls the
+// prefetched bytes out of the vector registers with v_readlane.  Same visited cells, same state machine as ksw_backtrack
+// (SR/ksw2.h:131-163); only the latency is hidden differently than in the one-walk-per-thread kernel above, which stays the
+// better choice for short reads (hundreds of thousands of 300-step walks).
+__global__ __launch_bounds__(256) void ksw_backtrack_wave_kernel(const KswTask *__restrict__ tasks, int n,
+                                                                 const uint8_t *__restrict__ bt,
+                                                                 const int32_t *__restrict__ status,
+                                                                 int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
+                                                                 uint32_t *__restrict__ cigar)
+{
+	const int lane = threadIdx.x & 63;
+	const int tid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+	if (tid >= n) return;
+	const int st = __builtin_amdgcn_readfirstlane(status[tid]);
+	if (st == GD_ST_EXACT) return;
+	if (st != GD_ST_DONE) {
+		if (lane == 0) {
+			n_cigar[tid] = 0;
+			if (st == GD_ST_ZDROPPED) score[tid] = GD_NEG_INF;
+		}
+		return;
+	}
+	const KswTask T = tasks[tid];
+	const int qlen = __builtin_amdgcn_readfirstlane(T.qlen), tlen = __builtin_amdgcn_readfirstlane(T.tlen);
+	const int w0 = __builtin_amdgcn_readfirstlane(T.w);
+	const int w = w0 < 0 ? (tlen > qlen ? tlen : qlen) : w0;
+	const int kind = __builtin_amdgcn_readfirstlane(T.kind);
+	const uint8_t *p = bt + T.bt_off;
+	uint32_t *cg = cigar + T.cig_off;
+	const int cap = __builtin_amdgcn_readfirstlane(T.cig_cap);
+	int nc = 0, i = tlen - 1, j = qlen - 1, state = 0, have = 0;
+	uint32_t last = 0;
+#define GD_PUSHW(op_, len_)                                                      \
+	do {                                                                         \
+		if (have && (last & 0xf) == (uint32_t)(op_)) last += (uint32_t)(len_) << 4; \
+		else {                                                                   \
+			if (have) { if (nc < cap && lane == 0) cg[nc] = last; ++nc; }        \
+			last = (uint32_t)(len_) << 4 | (uint32_t)(op_), have = 1;            \
+		}                                                                        \
+	} while (0)
+	while (i >= 0 && j >= 0) {
+		const int i0 = i, j0 = j;
+		const int ik = i0 - lane, jk = j0 - lane;
+		int fs = -1;
+		uint32_t pf = 0;
+		if (ik >= 0 && jk >= 0) {
+			const int r = ik + jk;
+			int st0, en0;
+			gd_band(r, qlen, tlen, w, st0, en0);
+			const int off = st0 & ~15, off_end = en0 | 15;
+			if (ik < off) fs = 2;
+			if (ik > off_end) fs = 1;
+			if (fs < 0) pf = p[gd_bt_index(T, r, ik, off)];
+		}
+		for (int k = 0; k < 64; ++k) {
+			if (i != i0 - k || j != j0 - k || i < 0 || j < 0) break; // left the fetched diagonal (or finished)
+			const int force_state = __builtin_amdgcn_readlane(fs, k);
+			uint32_t tmp = (uint32_t)__builtin_amdgcn_readlane((int)pf, k);
+			if (force_state < 0 && kind != GD_KIND_GENERIC) { // wave-kernel byte -> the reference's byte (see ksw_backtrack_kernel)
+				const uint32_t nb = ~tmp;
+				tmp = (4u - (tmp & 7u)) | ((nb >> 3) & 0x08u) | ((nb >> 1) & 0x10u) | ((nb << 1) & 0x20u) | ((nb << 3) & 0x40u);
+			}
+			if (state == 0) state = tmp & 7;
+			else if (!(tmp >> (state + 2) & 1)) state = 0;
+			if (state == 0) state = tmp & 7;
+			if (force_state >= 0) state = force_state;
+			if (state == 0) { GD_PUSHW(0, 1); --i, --j; }
+			else if (state == 1 || state == 3) { GD_PUSHW(2, 1); --i; }
+			else { GD_PUSHW(1, 1); --j; }
+		}
+	}
+	if (i >= 0) GD_PUSHW(2, i + 1);
+	if (j >= 0) GD_PUSHW(1, j + 1);
+	if (have) { if (nc < cap && lane == 0) cg[nc] = last; ++nc; }
+#undef GD_PUSHW
+	if (lane == 0) n_cigar[tid] = nc;
+	if (nc <= cap) { // reverse in place, 64 swaps at a time (the stores above are this wavefront's own: program order suffices)
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // lane 0 wrote the ops, all lanes read them
+		for (int k = lane; k < nc >> 1; k += 64) {
+			const uint32_t t0 = cg[k];
+			cg[k] = cg[nc - 1 - k], cg[nc - 1 - k] = t0;
+		}
+	}
+}

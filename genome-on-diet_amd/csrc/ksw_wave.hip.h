@@ -15,8 +15,9 @@
 // row_ror:1 (0x121; a DPP "row" is 16 lanes) for the 16-lane form
 template <int LANES> __device__ __forceinline__ u32 gdw_ror1(u32 v)
 {
-	if (LANES == 64) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false);
-	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);
+	// every lane has a source lane under a rotate, so no "old" value is needed: bound_ctrl form, no register to pre-clear
+	if (LANES == 64) return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x13C, 0xF, 0xF, true);
+	return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, true);
 }
 
 // the one fresh query byte per anti-diagonal, read through the scalar cache: an aligned dword at a wave-uniform address
