@@ -10,17 +10,19 @@ Workload = BASELINE.json configs[3], the configuration the metric is quoted on:
     GRCh38-sized reference (24 contigs with the GRCh38 primary-chromosome lengths, i.i.d. ACGT + a 5 % repeat layer at 2 %
     divergence + N runs).  `--ref-mbp` scales the reference down for quick runs (the JSON says which size ran).
 
-A "step" = one pass of the whole per-read path (gdiet_hip_map_uploaded: sketch2/shift/sketch3, seed filter + lookup, hit
-sort, vote/vote_2 on the GPU; candidate geometry on host threads; window gather, exact-match, ksw_extd2 DP, backtrack on
-the GPU; mm_update_extra / concatenate_cigars / mm_set_sam_params on host threads) over one batch of reads that is
-already resident in HBM.  value = bases of reads with >= 1 alignment / wall time, summed over ranks (reads are sharded
-over GPUs, index replicated, no collective).
+A "step" = one pass of the whole per-read path (sketch2/shift/sketch3, seed filter + lookup, hit sort, vote/vote_2 on the
+GPU; candidate geometry on host threads; window gather, exact-match, ksw_extd2 DP, backtrack on the GPU; mm_update_extra /
+concatenate_cigars / mm_set_sam_params on host threads) over one batch of reads that is already resident in HBM.  With the
+default --inflight 2 step i+1 is submitted (gdiet_hip_map_submit) before step i is waited for, so its seeding / voting / host
+stages overlap the DP kernel of step i; all K batches are complete when the timed region ends (--inflight 1 runs them one at
+a time).  value = bases of reads with >= 1 alignment / wall time, summed over ranks (reads are sharded over GPUs, index
+replicated, no collective).
 
 roofline: dominant kernel = ksw_extd2_wave_kernel<64>; achieved = algorithmic bytes of the launch (per alignment
 (qlen+tlen-1)*min(w+1,qlen,tlen) + (qlen+tlen) + qlen + ceil(tlen/2)) / its duration from HIP events on the launch stream.
 cpu_baseline: the reference binary itself (oracle/_ref/gdiet_lr_avx = GDiet_avx) where it travelled with the repo, mapping
-a bounded sample of the same reads against the contig they were drawn from, all host cores; else the DP stage of the
-oracle port on one core.
+a bounded sample of the same kind of reads against the contig they were drawn from, best of several thread counts (rank 0,
+N = 1 only); else the DP stage of the oracle port on one core.
 """
 import argparse
 import glob
@@ -282,7 +284,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(alg), "dp_cells_per_launch": int(cells), "gcups": cells / (dp * 1e-3) / 1e9, "kernel_ms": dp,
                          "backtrack_kernel_ms": bt},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
             try:
                 if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")):
                     out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), os.cpu_count() or 8)
