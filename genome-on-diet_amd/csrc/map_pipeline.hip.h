@@ -318,21 +318,30 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	int rc;
 	double t0 = gd_now();
 	// ---- scratch layout -------------------------------------------------------------------------------------------
+	// minimizer lists: len/3 + 512 entries per read cover every density the presets produce; a read that overflows its list
+	// (tiny windows, homopolymer reads) makes the whole batch retry once with the hard bound
 	std::vector<MapReadScratch> sc(n);
 	uint64_t tot = 0;
-	for (int i = 0; i < n; ++i) {
-		const uint32_t len = (uint32_t)(B.roff[i + 1] - B.roff[i]);
-		sc[i].mv_cap = len / 3 + 512, sc[i].mv_off = tot, sc[i].u64_off = 2 * tot, sc[i].seed_off = tot, sc[i].pad = 0;
-		tot += sc[i].mv_cap;
-	}
-	if ((rc = gd_grow(ctx, ctx->m_sc, sizeof(MapReadScratch) * n))) return rc;
-	if ((rc = gd_grow(ctx, ctx->m_mv, sizeof(GdMini) * tot))) return rc;
-	if ((rc = gd_grow(ctx, ctx->m_u64, sizeof(uint64_t) * 2 * tot))) return rc;
-	if ((rc = gd_grow(ctx, ctx->m_seed, sizeof(GdSeed) * tot))) return rc;
+	auto layout = [&](bool full) -> int {
+		tot = 0;
+		for (int i = 0; i < n; ++i) {
+			const uint32_t len = (uint32_t)(B.roff[i + 1] - B.roff[i]);
+			// hard bound: one minimizer per base, plus the per-lane staging lists of the wavefront sketch (64 lists of ceil(len/64) + w + 2)
+			sc[i].mv_cap = full ? len + 64 * (uint32_t)(O.w + 4) : len / 3 + 512, sc[i].mv_off = tot, sc[i].u64_off = 2 * tot, sc[i].seed_off = tot, sc[i].pad = 0;
+			tot += sc[i].mv_cap;
+		}
+		int rc2;
+		if ((rc2 = gd_grow(ctx, ctx->m_sc, sizeof(MapReadScratch) * n))) return rc2;
+		if ((rc2 = gd_grow(ctx, ctx->m_mv, sizeof(GdMini) * tot))) return rc2;
+		if ((rc2 = gd_grow(ctx, ctx->m_u64, sizeof(uint64_t) * 2 * tot))) return rc2;
+		if ((rc2 = gd_grow(ctx, ctx->m_seed, sizeof(GdSeed) * tot))) return rc2;
+		GD_HIP(hipMemcpyAsync(ctx->m_sc.p, sc.data(), sizeof(MapReadScratch) * n, hipMemcpyHostToDevice, s));
+		return GDIET_OK;
+	};
+	if ((rc = layout(false))) return rc;
 	if ((rc = gd_grow(ctx, ctx->m_seedout, sizeof(MapSeedOut) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->m_voteout, sizeof(MapVoteOut) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->m_hitoff, sizeof(int64_t) * (n + 1)))) return rc;
-	GD_HIP(hipMemcpyAsync(ctx->m_sc.p, sc.data(), sizeof(MapReadScratch) * n, hipMemcpyHostToDevice, s));
 	MapDevOpt D;
 	D.k = O.k, D.w = O.w, D.max_seeds = O.max_seeds, D.q_occ_frac = O.q_occ_frac, D.mid_occ = O.mid_occ, D.max_max_occ = O.max_max_occ, D.occ_dist = O.occ_dist;
 	D.max_nb_seeds = (O.flag & GD_F_FRAG_MODE) ? (O.max_frag_len == 0 ? 800u : (uint32_t)O.max_frag_len) : UINT32_MAX;
@@ -347,19 +356,25 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	const int64_t *d_roff = (const int64_t *)B.d_roff;
 	ctx->stage_s[5] += gd_now() - t0, t0 = gd_now();
 	// ---- S1-S5 ----------------------------------------------------------------------------------------------------
-	if (ctx->seed_thread_kernel) // one read per thread: the plain sequential form, kept for A/B checks (GDIET_SEED_KERNEL=thread)
-		hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
-		                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
-	else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
-		hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
-		                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 	std::vector<MapSeedOut> so(n);
-	GD_HIP(hipMemcpyAsync(so.data(), ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
-	GD_HIP(hipStreamSynchronize(s));
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if (ctx->seed_thread_kernel) // one read per thread: the plain sequential form, kept for A/B checks (GDIET_SEED_KERNEL=thread)
+			hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
+		else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
+			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
+		GD_HIP(hipMemcpyAsync(so.data(), ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
+		GD_HIP(hipStreamSynchronize(s));
+		bool overflow = false;
+		for (int i = 0; i < n; ++i) overflow |= so[i].n_seeds < 0;
+		if (!overflow) break;
+		if (attempt == 1) { ctx->err = "minimizer scratch overflow even with one entry per base"; return GDIET_E_NOMEM; }
+		if ((rc = layout(true))) return rc;
+	}
 	ctx->stage_s[0] += gd_now() - t0, t0 = gd_now();
 	std::vector<int64_t> hoff(n + 1, 0);
 	for (int i = 0; i < n; ++i) {
-		if (so[i].n_seeds < 0) { ctx->err = "minimizer scratch overflow for read " + std::to_string(i); return GDIET_E_NOMEM; }
 		hoff[i + 1] = hoff[i] + (so[i].n_seeds > 0 ? so[i].n_a : 0);
 	}
 	if ((rc = gd_grow(ctx, ctx->m_hits, sizeof(GdLoc) * 3 * (size_t)(hoff[n] + 1)))) return rc;

@@ -6,9 +6,14 @@ import os
 LR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lr")
 SR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sr")
 # kind -> (directory, read set / golden stem, Mapper preset)
-SETS = {"hifi": (LR, "hifi", "hifi"), "ont": (LR, "ont", "ont"), "sr": (SR, "sr", "sr"), "sr_var": (SR, "var", "sr")}
+# "hifi_w1": the first 8 reads of hifi.fq with -k 15 -w 1 (every sparsified base is a minimizer: the per-read scratch of the
+# seeding kernel overflows its first estimate and the batch is retried with the hard bound)
+# "*_edge": reads shorter than k / k+w, all-N, poly-A, lower case, IUPAC codes, chimeras, duplications, lengths around the 300 bp
+# switches of both variants, indels, reads flush with a contig start (golden: tools of the reference on these very files)
+SETS = {"hifi_edge": (LR, "edge_hifi", "hifi"), "ont_edge": (LR, "edge_ont", "ont"), "sr_edge": (SR, "edge", "sr"),
+        "hifi_w1": (LR, "w1", "hifi"), "hifi": (LR, "hifi", "hifi"), "ont": (LR, "ont", "ont"), "sr": (SR, "sr", "sr"), "sr_var": (SR, "var", "sr")}
 # options of var.cmd that differ from the sr preset (README command): -N 5 -n 0.3,0.1 -s 40 --AF_max_loc 20
-OVERRIDES = {"sr_var": dict(best_n=5, min_cnt=0.3, rec_threshold_frac=0.1, min_dp_max=40, AF_max_loc=20)}
+OVERRIDES = {"hifi_w1": dict(k=15, w=1), "sr_var": dict(best_n=5, min_cnt=0.3, rec_threshold_frac=0.1, min_dp_max=40, AF_max_loc=20)}
 
 
 def read_fasta(path):
@@ -36,3 +41,19 @@ def read_fastq(path):
 def golden_sam(kind):
     d, stem, _ = SETS[kind]
     return [l.rstrip("\n") for l in gzip.open(os.path.join(d, stem + ".golden.sam.gz"), "rt")]
+
+
+def reads_of(kind):
+    """the read set a golden SAM was made from"""
+    d, stem, _ = SETS[kind]
+    if kind == "hifi_w1":
+        return read_fastq(os.path.join(d, "hifi.fq.gz"))[:8]
+    if kind.endswith("_edge"):
+        return read_fastq(os.path.join(d, "edge.fq.gz"))
+    return read_fastq(os.path.join(d, stem + ".fq.gz"))
+
+
+def cmd_of(kind):
+    d, stem, _ = SETS[kind]
+    name = {"hifi_edge": "hifi", "ont_edge": "ont", "sr_edge": "sr"}.get(kind, stem)
+    return open(os.path.join(d, name + ".cmd")).read().split()

@@ -5,16 +5,16 @@ import os
 
 import pytest
 
-from fixture_io import LR, OVERRIDES, SETS, golden_sam, read_fasta, read_fastq
+from fixture_io import LR, OVERRIDES, SETS, golden_sam, read_fasta, read_fastq, reads_of
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var"])
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge"])
 def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
     base, stem, preset = SETS[kind]
     names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
-    reads = read_fastq(os.path.join(base, stem + ".fq.gz"))
+    reads = reads_of(kind)
     m = pkg.Mapper(gpu_ctx, names, seqs, preset=preset, **OVERRIDES.get(kind, {}))
     try:
         res = m.map([r[1] for r in reads])

@@ -10,7 +10,7 @@ import subprocess
 import pytest
 
 from conftest import ROOT
-from fixture_io import LR, SETS, SR, golden_sam
+from fixture_io import LR, SETS, SR, cmd_of, golden_sam, reads_of
 
 
 @pytest.fixture(scope="module")
@@ -28,13 +28,15 @@ def host_driver(tmp_path_factory):
     return exe, str(d)
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var"])
-def test_host_path_matches_golden_sam(host_driver, kind):
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge"])
+def test_host_path_matches_golden_sam(host_driver, kind, tmp_path):
     exe, d = host_driver
-    base, stem, _ = SETS[kind]
-    sub = os.path.join(d, os.path.basename(base))
-    cmd = open(os.path.join(base, stem + ".cmd")).read().split()
-    out = subprocess.run([exe] + cmd + [os.path.join(sub, "ref.fa"), os.path.join(sub, stem + ".fq")], capture_output=True, text=True, check=True)
+    base = SETS[kind][0]
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for name, seq, qual in reads_of(kind):
+            f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
+    out = subprocess.run([exe] + cmd_of(kind) + [os.path.join(d, os.path.basename(base), "ref.fa"), fq], capture_output=True, text=True, check=True)
     got = out.stdout.rstrip("\n").split("\n")
     want = golden_sam(kind)
     assert len(got) == len(want)
