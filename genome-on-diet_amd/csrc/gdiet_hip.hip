@@ -121,7 +121,7 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 	ctx->host_threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 	{
 		const char *e = getenv("GDIET_SEED_KERNEL");
-		ctx->seed_thread_kernel = e && !strcmp(e, "thread");
+		ctx->seed_thread_kernel = e && !strcmp(e, "thread") ? 1 : e && !strcmp(e, "wave") ? 2 : 0; // 0: by read length
 		const char *sl = getenv("GDIET_SLICES_PER_LANE");
 		if (sl && atoi(sl) > 0) ctx->slices_per_lane = atoi(sl);
 		const char *bw = getenv("GDIET_BT_WAVE");

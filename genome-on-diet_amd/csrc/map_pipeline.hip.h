@@ -3,6 +3,8 @@
 //   device       : map_seed_kernel -> map_vote_kernel -> map_gather_kernel -> ksw batch (exact-match, DP, backtrack)
 #pragma once
 #include <atomic>
+#include <memory>
+#include <cstddef>
 #include <chrono>
 #include <thread>
 #include <mutex>
@@ -358,7 +360,9 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// ---- S1-S5 ----------------------------------------------------------------------------------------------------
 	std::vector<MapSeedOut> so(n);
 	for (int attempt = 0; attempt < 2; ++attempt) {
-		if (ctx->seed_thread_kernel) // one read per thread: the plain sequential form, kept for A/B checks (GDIET_SEED_KERNEL=thread)
+		// one read per thread (the plain sequential form) for short reads -- a 150 bp read has ~75 sparsified bases, far too few to
+		// split over 64 lanes (measured 18x faster at 150 bp) -- and on request (GDIET_SEED_KERNEL=thread) for A/B checks
+		if (ctx->seed_thread_kernel == 1 || (ctx->seed_thread_kernel == 0 && (B.roff[n] - B.roff[0]) / n < 1024))
 			hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 		else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
@@ -380,21 +384,26 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	if ((rc = gd_grow(ctx, ctx->m_hits, sizeof(GdLoc) * 3 * (size_t)(hoff[n] + 1)))) return rc;
 	GD_HIP(hipMemcpyAsync(ctx->m_hitoff.p, hoff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s));
 	// ---- S6, S7, V1, V3, G1a -----------------------------------------------------------------------------------------
-	hipLaunchKernelGGL(map_vote_kernel, dim3(ctx->spread ? n : (n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+	const int spread = ctx->spread && (B.roff[n] - B.roff[0]) / n >= 1024; // long reads: one read per wavefront; short reads: per thread
+	hipLaunchKernelGGL(map_vote_kernel, dim3(spread ? n : (n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 	                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
-	                   (MapVoteOut *)ctx->m_voteout.p, ctx->spread);
-	std::vector<MapVoteOut> vo(n);
-	GD_HIP(hipMemcpyAsync(vo.data(), ctx->m_voteout.p, sizeof(MapVoteOut) * n, hipMemcpyDeviceToHost, s));
+	                   (MapVoteOut *)ctx->m_voteout.p, spread);
+	// only the head of every record can be in use: n_cand + at most AF_max_loc (ShortReads) / vt_nb_loc + 2 (LongReads) candidates;
+	// the host copy is packed to that size (a full-size array would be 680 B per read: 178 MB to allocate and clear per 262 k short reads)
+	const size_t vo_head = offsetof(MapVoteOut, cand) + sizeof(GdVt) * std::min<size_t>(is_sr ? (size_t)O.af_max_loc : (size_t)O.vt_nb_loc + 2, GDM_MAX_VT);
+	std::unique_ptr<uint8_t[]> vo_raw(new uint8_t[vo_head * (size_t)n]);
+	GD_HIP(hipMemcpy2DAsync(vo_raw.get(), vo_head, ctx->m_voteout.p, sizeof(MapVoteOut), vo_head, (size_t)n, hipMemcpyDeviceToHost, s));
 	GD_HIP(hipStreamSynchronize(s));
 	ctx->stage_s[1] += gd_now() - t0, t0 = gd_now();
 	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
 	const GdRefView R = ix->h.ref();
 	std::vector<std::vector<GdCand>> cand(n);
 	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
-		const unsigned nc = vo[i].n_cand;
+		const MapVoteOut &vo_i = *reinterpret_cast<const MapVoteOut *>(vo_raw.get() + vo_head * (size_t)i); // head of the record only
+		const unsigned nc = vo_i.n_cand;
 		if (!nc) return;
 		cand[i].resize(nc);
-		for (unsigned j = 0; j < nc; ++j) cand[i][j].v = vo[i].cand[j];
+		for (unsigned j = 0; j < nc; ++j) cand[i][j].v = vo_i.cand[j];
 		if (is_sr) gd_sr_boxes(cand[i], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
 		else gd_lr_link_and_boxes(cand[i], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
 	});

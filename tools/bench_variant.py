@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Whole-path throughput of the other two canonical configurations (BASELINE configs[2] ShortReads, configs[4] ONT) on one GPU.
+Not the headline bench (bench.py = configs[3]); same structure, smaller synthetic reference by default.
+
+    python tools/bench_variant.py --kind sr  [--batch 262144] [--ref-mbp 400] [--steps 5]
+    python tools/bench_variant.py --kind ont [--batch 256]    [--ref-mbp 400] [--steps 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # noqa: F401  (first: one HIP runtime for torch and libgdiet_hip.so)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from __graft_entry__ import _load_pkg  # noqa: E402
+
+
+def synth_reads(rng, contigs, n, kind):
+    lens = np.array([len(c) for c in contigs], np.float64)
+    cs = rng.choice(len(contigs), size=n, p=lens / lens.sum())
+    out = []
+    for i in range(n):
+        c = int(cs[i])
+        if kind == "sr":
+            ln, sub, ind = 150, 0.01, 0.0005
+        else:
+            ln, sub, ind = int(np.clip(rng.lognormal(np.log(50000), 0.35), 5000, 150000)), 0.03, 0.02
+        ln = min(ln, len(contigs[c]) - 2)
+        st = int(rng.integers(0, len(contigs[c]) - ln))
+        s = contigs[c][st:st + ln].copy()
+        m = np.flatnonzero((rng.random(ln) < sub) & (s != 78))
+        if len(m):
+            s[m] = bench.BASES[(np.searchsorted(bench.BASES, s[m]) + rng.integers(1, 4, size=len(m))) & 3]
+        if kind != "sr" or rng.random() < 0.15:
+            s = s[~(rng.random(len(s)) < ind)]
+            ip = np.flatnonzero(rng.random(len(s)) < ind)
+            s = np.insert(s, ip, bench.BASES[rng.integers(0, 4, size=len(ip))])
+        if rng.random() < 0.5:
+            s = bench.COMP[s[::-1]]
+        out.append(s.tobytes())
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", choices=["sr", "ont"], required=True)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--ref-mbp", type=float, default=400)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--inflight", type=int, default=1)
+    a = ap.parse_args()
+    n = a.batch or (262144 if a.kind == "sr" else 256)
+    pkg = _load_pkg()
+    ctx = pkg.Context(0)
+    names, contigs = bench.synth_reference(a.ref_mbp, seed=2)
+    t0 = time.time()
+    m = pkg.Mapper(ctx, names, contigs, preset=a.kind, n_threads=os.cpu_count() or 8)
+    t_idx = time.time() - t0
+    m.set_host_threads(min(256, os.cpu_count() or 8))
+    reads = synth_reads(np.random.default_rng(7), contigs, n, a.kind)
+    batch = m.upload(reads)
+    bases = sum(len(r) for r in reads)
+    res = m.map_uploaded(batch)  # warm-up
+    st, t0 = [], time.perf_counter()
+    for _ in range(a.steps):
+        res = m.map_uploaded(batch)
+        st.append(m.stage_seconds())
+    dt = (time.perf_counter() - t0) / a.steps
+    mapped = sum(len(reads[i]) for i in range(n) if res.n_regs[i] > 0)
+    dp, bt = ctx.last_kernel_ms()
+    cells, alg = ctx.last_dp_work()
+    s = np.mean(np.array(st), axis=0)
+    print(json.dumps({"kind": a.kind, "reads_per_step": n, "bases_per_step": bases, "mapped_fraction": mapped / bases, "ms_per_step": 1e3 * dt,
+                      "mapped_Mbases_per_s": mapped / dt / 1e6, "reads_per_s": n / dt, "index_build_s": round(t_idx, 1), "ref_mbp": a.ref_mbp,
+                      "stage_ms": {"seed": 1e3 * s[0], "vote": 1e3 * s[1], "host_geometry": 1e3 * s[2], "gather_dp_backtrack": 1e3 * s[3],
+                                   "host_post": 1e3 * s[4], "other": 1e3 * s[5]},
+                      "dp_kernel_ms": dp, "backtrack_ms": bt, "dp_gcups": cells / dp / 1e6 if dp else None, "kernel_mask": ctx.last_kernel_mask()}))
+
+
+if __name__ == "__main__":
+    main()
