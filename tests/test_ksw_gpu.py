@@ -137,3 +137,73 @@ def test_short_read_quartets_match_oracle(gpu_ctx, pkg, oracle):
         assert sc[i] == o["score"], (i, len(qs[i]), len(ts[i]), ws[i], sc[i], o["score"])
         assert np.array_equal(cg[i], o["cigar"]), (i, len(qs[i]), len(ts[i]), ws[i])
     assert n_exact >= 30
+
+
+def test_device_pointer_entry_matches_host_entry(gpu_ctx, pkg, oracle):
+    """gdiet_hip_ksw_extd2_batch_dev: everything resident in HBM (torch tensors), launched on a torch stream, never synchronises"""
+    import torch
+    gdo, _ = oracle
+    rng = np.random.default_rng(9)
+    qs, ts = [], []
+    for i in range(40):
+        q, t = gdo.make_pair(rng, int(rng.integers(100, 3000)), 0.01, 0.003, 0.003)
+        qs.append(q), ts.append(t)
+    w = np.full(len(qs), 300, np.int32)
+    score = pkg.KswScore.from_preset("hifi")
+    want_sc, want_cg = gpu_ctx.ksw_extd2_batch(qs, ts, 300, score)
+    qbuf, qoff = pkg.pack(qs)
+    tbuf, toff = pkg.pack(ts)
+    coff = np.zeros(len(qs) + 1, np.int64)
+    coff[1:] = np.cumsum([len(q) + len(t) for q, t in zip(qs, ts)])
+    dev = torch.device("cuda", 0)
+    d_q, d_t = torch.from_numpy(qbuf).to(dev), torch.from_numpy(tbuf).to(dev)
+    d_coff = torch.from_numpy(coff).to(dev)
+    d_sc = torch.zeros(len(qs), dtype=torch.int32, device=dev)
+    d_nc = torch.zeros(len(qs), dtype=torch.int32, device=dev)
+    d_cg = torch.zeros(int(coff[-1]) + 1, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        gpu_ctx.ksw_extd2_batch_dev(len(qs), d_q.data_ptr(), d_t.data_ptr(), None, score, d_sc.data_ptr(), d_nc.data_ptr(), d_cg.data_ptr(),
+                                    d_coff.data_ptr(), qoff, toff, w, stream=st.cuda_stream)
+    st.synchronize()
+    sc, nc, cg = d_sc.cpu().numpy(), d_nc.cpu().numpy(), d_cg.cpu().numpy().view(np.uint32)
+    for i in range(len(qs)):
+        assert sc[i] == want_sc[i] and np.array_equal(cg[coff[i]:coff[i] + nc[i]], want_cg[i])
+    dp_ms, bt_ms = gpu_ctx.last_kernel_ms()
+    assert dp_ms > 0 and bt_ms > 0
+    cells, alg = gpu_ctx.last_dp_work()
+    assert cells == sum((len(q) + len(t) - 1) * min(301, len(q), len(t)) for q, t in zip(qs, ts)) and alg > cells
+
+
+def test_error_behaviour_of_the_abi(gpu_ctx, pkg):
+    """argument errors are reported, never answered approximately (no CPU fallback, no silent truncation)"""
+    import ctypes as C
+    lib = pkg.load_library()
+    score = pkg.KswScore.from_preset("sr")
+    q = np.zeros(50, np.uint8)
+    assert gpu_ctx.ksw_extd2_batch([], [], 10, score)[0].size == 0  # n = 0 is fine
+    with pytest.raises(pkg.GdietError):  # an empty sequence: the reference returns without aligning
+        gpu_ctx.ksw_extd2_batch([q, np.zeros(0, np.uint8)], [q, q], 10, score)
+    bad = pkg.KswScore.from_preset("sr")
+    bad.flag = 0x40  # KSW_EZ_EXTZ_ONLY: not a mode of the live path
+    with pytest.raises(pkg.GdietError):
+        gpu_ctx.ksw_extd2_batch([q], [q], 10, bad)
+    bad = pkg.KswScore.from_preset("sr")
+    bad.q, bad.e = 1, 1
+    bad.mismatch = -100  # -min_sc > 2(q+e): ksw_extd2 returns without aligning
+    with pytest.raises(pkg.GdietError):
+        gpu_ctx.ksw_extd2_batch([q], [q], 10, bad)
+    # CIGAR capacity too small: error code -5 and the needed size in n_cigar
+    rng = np.random.default_rng(2)
+    t = rng.integers(0, 4, size=200, dtype=np.uint8)
+    qq = np.concatenate([t[:80], t[90:150], rng.integers(0, 4, size=7, dtype=np.uint8), t[150:]])
+    qoff, toff = np.array([0, len(qq)], np.int64), np.array([0, len(t)], np.int64)
+    w, sc, nc = np.array([100], np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    cg, coff = np.zeros(4, np.uint32), np.array([0, 2], np.int64)
+    p = lambda a, ty: a.ctypes.data_as(C.POINTER(ty))
+    rc = lib.gdiet_hip_ksw_extd2_batch(gpu_ctx._h, 1, p(qq, C.c_uint8), p(qoff, C.c_int64), p(t, C.c_uint8), p(toff, C.c_int64), p(w, C.c_int32),
+                                       None, C.byref(score), p(sc, C.c_int32), p(nc, C.c_int32), p(cg, C.c_uint32), p(coff, C.c_int64))
+    assert rc == -5 and nc[0] > 2
+    assert lib.gdiet_hip_ksw_extd2_batch(None, 1, None, None, None, None, None, None, None, None, None, None, None) == -3
+    ctx2 = C.c_void_p()
+    assert lib.gdiet_hip_init(C.byref(ctx2), 99) == -1  # no such device: GDIET_E_NODEVICE

@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--kind", choices=["sr", "ont"], required=True)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--ref-mbp", type=float, default=400)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--inflight", type=int, default=1)
     a = ap.parse_args()
     n = a.batch or (262144 if a.kind == "sr" else 256)
@@ -66,9 +66,22 @@ def main():
     batch = m.upload(reads)
     bases = sum(len(r) for r in reads)
     res = m.map_uploaded(batch)  # warm-up
-    st, t0 = [], time.perf_counter()
+    if a.inflight > 1:
+        m.set_inflight(a.inflight)
+        for t in [m.submit(batch) for _ in range(a.inflight)]:  # every lane allocates its scratch once
+            res = m.wait(t)
+    st, open_t, t0 = [], [], time.perf_counter()
     for _ in range(a.steps):
-        res = m.map_uploaded(batch)
+        if a.inflight == 1:
+            res = m.map_uploaded(batch)
+            st.append(m.stage_seconds())
+        else:
+            open_t.append(m.submit(batch))
+            if len(open_t) == a.inflight:
+                res = m.wait(open_t.pop(0))
+                st.append(m.stage_seconds())
+    while open_t:
+        res = m.wait(open_t.pop(0))
         st.append(m.stage_seconds())
     dt = (time.perf_counter() - t0) / a.steps
     mapped = sum(len(reads[i]) for i in range(n) if res.n_regs[i] > 0)
