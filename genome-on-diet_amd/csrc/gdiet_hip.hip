@@ -34,6 +34,10 @@ struct gdiet_ctx {
 	DevBuf tasks, ids, status;  // per-batch descriptors
 	DevBuf qseq, tseq, score, ncig, cigar; // host-API staging
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	// head / tail split of a big DP launch (see gdiet_hip_ksw_extd2_batch_dev)
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev2[3] = {nullptr, nullptr, nullptr}; // go, DP of the tail done, tail done
+	int dp_split = 1, wave_slots = 5120, last_split = 0;
 	std::vector<KswTask> h_tasks;
 	std::vector<int32_t> h_ids;
 	// per-read mapping path (map_pipeline.hip.h)
@@ -118,6 +122,10 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 			delete ctx;
 			return GDIET_E_HIP;
 		}
+	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
+	for (int i = 0; i < 3; ++i)
+		if (hipEventCreate(&ctx->ev2[i]) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
+	ctx->wave_slots = prop.multiProcessorCount * 4 * 5; // CUs x SIMDs x resident wavefronts of the 64-lane DP kernel (94 VGPRs)
 	ctx->host_threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 	{
 		const char *e = getenv("GDIET_SEED_KERNEL");
@@ -126,6 +134,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (sl && atoi(sl) > 0) ctx->slices_per_lane = atoi(sl);
 		const char *bw = getenv("GDIET_BT_WAVE");
 		if (bw) ctx->bt_wave = atoi(bw) != 0;
+		const char *ds = getenv("GDIET_DP_SPLIT");
+		if (ds) ctx->dp_split = atoi(ds) != 0;
 		const char *sp = getenv("GDIET_SPREAD");
 		if (sp) ctx->spread = atoi(sp) != 0;
 	}
@@ -152,6 +162,9 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 		if (b->p) (void)hipFree(b->p);
 	for (int i = 0; i < 4; ++i)
 		if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+	for (int i = 0; i < 3; ++i)
+		if (ctx->ev2[i]) (void)hipEventDestroy(ctx->ev2[i]);
+	if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -171,6 +184,14 @@ extern "C" int gdiet_hip_set_kernel_mode(gdiet_ctx *ctx, int mode)
 {
 	if (!ctx || mode < 0 || mode > 2) return GDIET_E_PARAM;
 	ctx->kernel_mode = mode;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_set_dp_split(gdiet_ctx *ctx, int on)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	ctx->dp_split = on != 0;
+	for (int i = 0; i < 4; ++i) if (ctx->async_lane[i]) ctx->async_lane[i]->dp_split = ctx->dp_split;
 	return GDIET_OK;
 }
 
@@ -362,9 +383,32 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	GD_HIP(hipEventRecord(ctx->ev[0], stream));
 	hipLaunchKernelGGL(ksw_exact_match_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_qseq, d_tseq,
 	                   d_status, d_score, d_n_cigar, d_cigar);
-	if (!ids[GD_KIND_WAVE64].empty())
-		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], (int)ids[GD_KIND_WAVE64].size(), d_qseq, d_tseq, d_bt,
-		                 d_status, d_score, K, stream);
+	// Head / tail split of a big 64-lane launch.  The grid is sorted longest-first, so the first `wave_slots` alignments start at
+	// once and the rest fill in as slots free up -- it is the latter that finish last.  Launched as two kernels (head on the
+	// caller's stream, tail on a second one), the head's backtrack runs while the tail is still in the DP, and only the tail's
+	// (shorter, fewer) walks remain after the last DP wavefront.  Same kernels, same work, same results.
+	const int n64 = (int)ids[GD_KIND_WAVE64].size();
+	const bool split = ctx->dp_split && n64 > ctx->wave_slots + ctx->wave_slots / 8;
+	const int n_head = split ? ctx->wave_slots : n64;
+	const bool bt_wave = ctx->bt_wave && cells_sum / (uint64_t)n > 200000; // long walks: one wavefront each; short reads: one walk per thread
+	auto backtrack = [&](const int32_t *list, int cnt, hipStream_t st) {
+		if (cnt <= 0) return;
+		if (bt_wave) hipLaunchKernelGGL(ksw_backtrack_wave_kernel, dim3((cnt + 3) / 4), dim3(256), 0, st, d_tasks, cnt, d_bt, d_status, d_score, d_n_cigar, d_cigar, list);
+		else hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((cnt + 63) / 64), dim3(64), 0, st, d_tasks, cnt, d_bt, d_status, d_score, d_n_cigar, d_cigar, 0, list);
+	};
+	ctx->last_split = split;
+	if (split) {
+		GD_HIP(hipEventRecord(ctx->ev2[0], stream)); // the tail may start once the pre-filter has answered
+		GD_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev2[0], 0));
+	}
+	if (n64 > 0)
+		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, split ? 1 : 0);
+	if (split) {
+		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64] + n_head, n64 - n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, ctx->stream2, 2);
+		GD_HIP(hipEventRecord(ctx->ev2[1], ctx->stream2));
+		backtrack(d_ids + id_off[GD_KIND_WAVE64] + n_head, n64 - n_head, ctx->stream2);
+		GD_HIP(hipEventRecord(ctx->ev2[2], ctx->stream2));
+	}
 	if (!ids[GD_KIND_WAVE16].empty())
 		gd_launch_wave16(d_tasks, d_ids + id_off[GD_KIND_WAVE16], (int)(quartets.size() / 4), d_qseq, d_tseq, d_bt,
 		                 d_status, d_score, K, stream);
@@ -379,12 +423,11 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		                   d_tasks, d_ids + id_off[GD_KIND_GENERIC], d_qseq, d_tseq, d_bt, d_status, d_score, K, max_cap);
 	}
 	GD_HIP(hipEventRecord(ctx->ev[1], stream));
-	// long walks: one wavefront each (64-cell diagonal prefetch + scalar walk); short reads: one walk per thread
-	if (ctx->bt_wave && cells_sum / (uint64_t)n > 200000)
-		hipLaunchKernelGGL(ksw_backtrack_wave_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, d_tasks, n, d_bt, d_status, d_score, d_n_cigar, d_cigar);
-	else
-		hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_bt, d_status, d_score,
-		                   d_n_cigar, d_cigar, 0);
+	if (split) { // everything but the tail: the lists of the four kinds sit back to back in d_ids, the tail is the end of the 64-lane list
+		backtrack(d_ids, (int)id_off[GD_KIND_WAVE64] + n_head, stream);
+		backtrack(d_ids + id_off[GD_KIND_WAVE64] + n64, (int)(ctx->h_ids.size() - id_off[GD_KIND_WAVE64] - n64), stream);
+		GD_HIP(hipStreamWaitEvent(stream, ctx->ev2[2], 0)); // join: later work on the caller's stream sees the tail's results too
+	} else backtrack(d_ids, (int)ctx->h_ids.size(), stream);
 	GD_HIP(hipEventRecord(ctx->ev[2], stream));
 	GD_HIP(hipGetLastError());
 	return GDIET_OK;
@@ -403,7 +446,13 @@ extern "C" int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *bt_
 	if (!ctx) return GDIET_E_PARAM;
 	float a = 0, b = 0;
 	GD_HIP(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-	GD_HIP(hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+	if (ctx->last_split) { // the DP phase ends with the later of the two launches
+		float a2 = 0;
+		GD_HIP(hipEventElapsedTime(&a2, ctx->ev[0], ctx->ev2[1]));
+		a = std::max(a, a2);
+	}
+	GD_HIP(hipEventElapsedTime(&b, ctx->ev[0], ctx->ev[2]));
+	b -= a; // what remains after the last DP wavefront
 	if (dp_ms) *dp_ms = a;
 	if (bt_ms) *bt_ms = b;
 	return GDIET_OK;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
                                                            const uint8_t *__restrict__ bt,
                                                            const int32_t *__restrict__ status,
                                                            int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
-                                                           uint32_t *__restrict__ cigar, int spread)
+                                                           uint32_t *__restrict__ cigar, int spread, const int32_t *__restrict__ task_ids)
 {
 	// spread = 1: one alignment per WAVEFRONT (lane 0 walks, the other lanes idle).  Kept for experiments only: it measured 2x
 	// SLOWER than one walk per thread, whose 64 x 16 prefetched loads per wavefront hide the latency better.
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 		tid >>= 6;
 	}
 	if (tid >= n) return;
+	if (task_ids) { tid = task_ids[tid]; if (tid < 0) return; } // a sub-list of the batch (-1: padding of a 16-lane quartet)
 	const int st = status[tid];
 	if (st == GD_ST_EXACT) return;
 	if (st != GD_ST_DONE) { // band emptied (zdropped): no CIGAR, score stays KSW_NEG_INF (SR/ksw2_extd2_sse.c:142-145,391)
@@ -150,11 +151,12 @@ __global__ __launch_bounds__(256) void ksw_backtrack_wave_kernel(const KswTask *
                                                                  const uint8_t *__restrict__ bt,
                                                                  const int32_t *__restrict__ status,
                                                                  int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
-                                                                 uint32_t *__restrict__ cigar)
+                                                                 uint32_t *__restrict__ cigar, const int32_t *__restrict__ task_ids)
 {
 	const int lane = threadIdx.x & 63;
-	const int tid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+	int tid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
 	if (tid >= n) return;
+	if (task_ids) { tid = __builtin_amdgcn_readfirstlane(task_ids[tid]); if (tid < 0) return; }
 	const int st = __builtin_amdgcn_readfirstlane(status[tid]);
 	if (st == GD_ST_EXACT) return;
 	if (st != GD_ST_DONE) {

@@ -58,7 +58,9 @@ static inline bool gd_wave_supported(int qlen, int tlen, int w, int lanes)
 //              (task_ids[4*slot + row]; -1 = empty row, which shadows row 0 without storing).  Identical geometry keeps every
 //              band / boundary quantity of the row loop wave-uniform (SGPRs), exactly as in the 64-lane form; only the
 //              sequence and backtrace pointers differ between the rows.  Short reads (150 x 150) all share one geometry.
-template <int LANES>
+// TAG only names the launch (0: a whole batch; 1 / 2: the head / tail launch of a split batch, see gdiet_hip.hip) so that a
+// profile lists them apart.
+template <int LANES, int TAG = 0>
 __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
                                                              const int32_t *__restrict__ task_ids, int n_slots,
                                                              const uint8_t *__restrict__ qseq,
@@ -155,11 +157,13 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 }
 
 static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
-                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s)
+                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int tag = 0)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	hipLaunchKernelGGL(ksw_extd2_wave_kernel<64>, dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+	if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
 }
 // ids: 4 task ids per wavefront (identical geometry; -1 pads an incomplete quartet), n_quartets wavefronts
 static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, int n_quartets, const uint8_t *q, const uint8_t *t,
@@ -167,7 +171,7 @@ static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, in
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	hipLaunchKernelGGL(ksw_extd2_wave_kernel<16>, dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
+	hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
 }
 
 // ---- wide bands (ONT, w = 1300): 128 blocks in flight, TWO per lane ------------------------------------------------------

@@ -58,6 +58,7 @@ def load_library():
     lib.gdiet_hip_last_kernel_mask.argtypes = [vp]
     lib.gdiet_hip_set_kernel_mode.argtypes = [vp, C.c_int]
     lib.gdiet_hip_reserve.argtypes = [vp, C.c_size_t]
+    lib.gdiet_hip_set_dp_split.argtypes = [vp, C.c_int]
     lib.gdiet_hip_ksw_workspace_bytes.argtypes = [C.c_int, i64p, i64p, i32p]
     lib.gdiet_hip_ksw_workspace_bytes.restype = C.c_size_t
     lib.gdiet_hip_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -116,6 +117,9 @@ class Context:
 
     def set_kernel_mode(self, mode):
         self._check(self.lib.gdiet_hip_set_kernel_mode(self._h, mode))
+
+    def set_dp_split(self, on):
+        self._check(self.lib.gdiet_hip_set_dp_split(self._h, int(on)))
 
     def last_kernel_mask(self):
         return self.lib.gdiet_hip_last_kernel_mask(self._h)

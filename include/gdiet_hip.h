@@ -114,6 +114,10 @@ size_t gdiet_hip_ksw_workspace_bytes(int n, const int64_t *qoff, const int64_t *
 /* restrict dispatch: 0 = automatic (default), 1 = force the generic LDS kernel, 2 = wave kernel only (fails
  * with GDIET_E_PARAM for alignments it cannot take).  For tests and A/B measurements. */
 int gdiet_hip_set_kernel_mode(gdiet_ctx *ctx, int mode);
+/* 1 (default): a 64-lane DP launch with more alignments than the GPU holds at once is issued as a head launch (the longest
+ * alignments, one per resident wavefront slot) and a tail launch on a second stream, so that the head's backtrack overlaps the
+ * tail's DP.  0: one launch, one backtrack (what bench.py uses for its roofline passes: one kernel, one duration). */
+int gdiet_hip_set_dp_split(gdiet_ctx *ctx, int on);
 /* average device time (ms, HIP events on the launch stream) of the DP kernel(s) and of the backtrack kernel of the
  * most recent *_dev / host batch; only valid after the stream has been synchronised. */
 int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *backtrack_ms);
