@@ -13,7 +13,7 @@ Workload = BASELINE.json configs[3], the configuration the metric is quoted on:
 A "step" = one pass of the whole per-read path (sketch2/shift/sketch3, seed filter + lookup, hit sort, vote/vote_2 on the
 GPU; candidate geometry on host threads; window gather, exact-match, ksw_extd2 DP, backtrack on the GPU; mm_update_extra /
 concatenate_cigars / mm_set_sam_params on host threads) over one batch of reads that is already resident in HBM.  With the
-default --inflight 2 step i+1 is submitted (gdiet_hip_map_submit) before step i is waited for, so its seeding / voting / host
+default --inflight 3 steps i+1 and i+2 are submitted (gdiet_hip_map_submit) before step i is waited for, so their seeding / voting / host
 stages overlap the DP kernel of step i; all K batches are complete when the timed region ends (--inflight 1 runs them one at
 a time).  value = bases of reads with >= 1 alignment / wall time, summed over ranks (reads are sharded over GPUs, index
 replicated, no collective).
@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--ref-mbp", type=float, default=float(os.environ.get("GDIET_BENCH_REF_MBP", "3088")),
                     help="size of the synthetic reference in Mbp (default: GRCh38-sized)")
     ap.add_argument("--lanes", type=int, default=1, help="software-pipeline depth inside a step (gdiet_hip_set_map_lanes)")
-    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3, 4],
+    ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight (gdiet_hip_map_submit/_wait): 2 overlaps the seeding/voting/host stages of step i+1 with the DP kernel of step i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -200,7 +200,7 @@ def main():
     if args.inflight > 1:
         mapper.set_inflight(args.inflight)
     def run_steps(k, stages=None):
-        """k passes over the batch; with --inflight 2 step i+1 is submitted before step i is waited for"""
+        """k passes over the batch; with --inflight N the next N-1 steps are submitted before step i is waited for"""
         last, open_t = None, []
         for _ in range(k):
             if args.inflight == 1:

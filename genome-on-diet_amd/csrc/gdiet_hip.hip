@@ -36,6 +36,7 @@ struct gdiet_ctx {
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	// head / tail split of a big DP launch (see gdiet_hip_ksw_extd2_batch_dev)
 	hipStream_t stream2 = nullptr;
+	hipStream_t stream_dp = nullptr;   // stream of the DP stage in an async lane (GDIET_DP_PRIORITY=1 raises its priority)
 	hipEvent_t ev2[3] = {nullptr, nullptr, nullptr}; // go, DP of the tail done, tail done
 	int dp_split = 1, wave_slots = 5120, last_split = 0;
 	std::vector<KswTask> h_tasks;
@@ -122,7 +123,14 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 			delete ctx;
 			return GDIET_E_HIP;
 		}
-	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
+	{
+		int lo = 0, hi = 0; // numerically lower = higher priority
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+		const char *pe = getenv("GDIET_DP_PRIORITY");
+		const bool prio = pe && atoi(pe) != 0; // measured: no gain from a raised priority, the separate stream is what matters
+		if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio ? hi : lo) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
+		if (hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamNonBlocking, prio ? hi : lo) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
+	}
 	for (int i = 0; i < 3; ++i)
 		if (hipEventCreate(&ctx->ev2[i]) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
 	ctx->wave_slots = prop.multiProcessorCount * 4 * 5; // CUs x SIMDs x resident wavefronts of the 64-lane DP kernel (94 VGPRs)
@@ -165,6 +173,7 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	for (int i = 0; i < 3; ++i)
 		if (ctx->ev2[i]) (void)hipEventDestroy(ctx->ev2[i]);
 	if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+	if (ctx->stream_dp) (void)hipStreamDestroy(ctx->stream_dp);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }

@@ -466,12 +466,14 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			dp_lock = std::unique_lock<std::mutex>(ctx->parent->dp_mu);
 			ctx->stage_s[5] += gd_now() - tw, t0 += gd_now() - tw; // waiting for the other batch's DP is not this batch's stage time
 		}
+		// in an async lane the DP stage has a stream of its own (everything queued on s is done: the synchronisation above)
+		hipStream_t sd = ctx->parent ? ctx->stream_dp : s;
 		rc = gdiet_hip_ksw_extd2_batch_dev(ctx, nb, (const uint8_t *)ctx->m_q.p, nullptr, (const uint8_t *)ctx->m_t.p, nullptr, nullptr, d_ex, &ks, d_score, d_ncig,
-		                                   (uint32_t *)ctx->m_cig.p, d_coff, qoff.data(), toff.data(), bw.data(), s);
+		                                   (uint32_t *)ctx->m_cig.p, d_coff, qoff.data(), toff.data(), bw.data(), sd);
 		if (rc) return rc;
-		GD_HIP(hipMemcpyAsync(h_score.data(), d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s));
-		GD_HIP(hipMemcpyAsync(h_ncig.data(), d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s));
-		GD_HIP(hipStreamSynchronize(s));
+		GD_HIP(hipMemcpyAsync(h_score.data(), d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
+		GD_HIP(hipMemcpyAsync(h_ncig.data(), d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
+		GD_HIP(hipStreamSynchronize(sd));
 		if (dp_lock.owns_lock()) dp_lock.unlock(); // backtrack done: the CIGARs sit in this lane's own buffer
 		// CIGARs are short compared with their capacity (qlen+tlen): pack them on the device, then one copy
 		for (int b = 0; b < nb; ++b) if (h_ncig[b] > coff[b + 1] - coff[b]) { ctx->err = "CIGAR capacity exceeded"; return GDIET_E_CIGAR_CAP; }
