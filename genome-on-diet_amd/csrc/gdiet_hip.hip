@@ -39,6 +39,7 @@ struct gdiet_ctx {
 	hipStream_t stream_dp = nullptr;   // stream of the DP stage in an async lane (GDIET_DP_PRIORITY=1 raises its priority)
 	hipEvent_t ev2[3] = {nullptr, nullptr, nullptr}; // go, DP of the tail done, tail done
 	int dp_split = 1, wave_slots = 5120, last_split = 0;
+	bool single_affine = false;        // set for the duration of a gdiet_hip_ksw_extz2_batch call: single-affine kernel variants
 	std::vector<KswTask> h_tasks;
 	std::vector<int32_t> h_ids;
 	// per-read mapping path (map_pipeline.hip.h)
@@ -397,7 +398,8 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	// caller's stream, tail on a second one), the head's backtrack runs while the tail is still in the DP, and only the tail's
 	// (shorter, fewer) walks remain after the last DP wavefront.  Same kernels, same work, same results.
 	const int n64 = (int)ids[GD_KIND_WAVE64].size();
-	const bool split = ctx->dp_split && n64 > ctx->wave_slots + ctx->wave_slots / 8;
+	const bool single = ctx->single_affine && K.q == K.q2 && K.e == K.e2;
+	const bool split = !single && ctx->dp_split && n64 > ctx->wave_slots + ctx->wave_slots / 8;
 	const int n_head = split ? ctx->wave_slots : n64;
 	const bool bt_wave = ctx->bt_wave && cells_sum / (uint64_t)n > 200000; // long walks: one wavefront each; short reads: one walk per thread
 	auto backtrack = [&](const int32_t *list, int cnt, hipStream_t st) {
@@ -411,7 +413,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		GD_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev2[0], 0));
 	}
 	if (n64 > 0)
-		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, split ? 1 : 0);
+		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, split ? 1 : 0, single);
 	if (split) {
 		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64] + n_head, n64 - n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, ctx->stream2, 2);
 		GD_HIP(hipEventRecord(ctx->ev2[1], ctx->stream2));
@@ -420,7 +422,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	}
 	if (!ids[GD_KIND_WAVE16].empty())
 		gd_launch_wave16(d_tasks, d_ids + id_off[GD_KIND_WAVE16], (int)(quartets.size() / 4), d_qseq, d_tseq, d_bt,
-		                 d_status, d_score, K, stream);
+		                 d_status, d_score, K, stream, single);
 	if (!ids[GD_KIND_WAVE128].empty())
 		gd_launch_wave128(d_tasks, d_ids + id_off[GD_KIND_WAVE128], (int)ids[GD_KIND_WAVE128].size(), d_qseq, d_tseq, d_bt,
 		                  d_status, d_score, K, stream);
@@ -523,7 +525,10 @@ extern "C" int gdiet_hip_ksw_extz2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 	if (!sc) { ctx->err = "scoring is NULL"; return GDIET_E_PARAM; }
 	gdiet_ksw_score_t s2 = *sc;
 	s2.q2 = sc->q, s2.e2 = sc->e; // ksw_extz2(q,e) == ksw_extd2(q,e,q,e) cell for cell in APPROX_MAX mode (see include/gdiet_hip.h)
-	return gdiet_hip_ksw_extd2_batch(ctx, n, qseq, qoff, tseq, toff, w, nullptr, &s2, score, n_cigar, cigar, cigar_off);
+	ctx->single_affine = true;     // the 16- and 64-lane kernels then run their single-affine form (no X2 / Y2 half)
+	const int rc = gdiet_hip_ksw_extd2_batch(ctx, n, qseq, qoff, tseq, toff, w, nullptr, &s2, score, n_cigar, cigar, cigar_off);
+	ctx->single_affine = false;
+	return rc;
 }
 
 #include "map_pipeline.hip.h"

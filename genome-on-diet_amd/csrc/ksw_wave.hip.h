@@ -60,7 +60,8 @@ static inline bool gd_wave_supported(int qlen, int tlen, int w, int lanes)
 //              sequence and backtrace pointers differ between the rows.  Short reads (150 x 150) all share one geometry.
 // TAG only names the launch (0: a whole batch; 1 / 2: the head / tail launch of a split batch, see gdiet_hip.hip) so that a
 // profile lists them apart.
-template <int LANES, int TAG = 0>
+// DUAL = false is the single-affine (ksw_extz2) form of the same kernel: see gdw_compute.
+template <int LANES, int TAG = 0, bool DUAL = true>
 __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
                                                              const int32_t *__restrict__ task_ids, int n_slots,
                                                              const uint8_t *__restrict__ qseq,
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 		// (4) DP cells of the lanes inside the reference's 16-aligned window
 		if (L.blk <= W.en_) {
 			u32 out[4];
-			gdw_compute(L, K, W, pX, pV, pX2, out);
+			gdw_compute<DUAL>(L, K, W, pX, pV, pX2, out);
 			if (LANES == 64 || live) *reinterpret_cast<uint4 *>(p + (size_t)r * (LANES * 16)) = make_uint4(out[0], out[1], out[2], out[3]);
 		}
 		// (5) score trackers
@@ -157,21 +158,23 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 }
 
 static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
-                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int tag = 0)
+                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int tag = 0, bool single = false)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0, false>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+	else if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
 	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
 	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
 }
 // ids: 4 task ids per wavefront (identical geometry; -1 pads an incomplete quartet), n_quartets wavefronts
 static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, int n_quartets, const uint8_t *q, const uint8_t *t,
-                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s)
+                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, bool single = false)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
+	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0, false>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
+	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
 }
 
 // ---- wide bands (ONT, w = 1300): 128 blocks in flight, TWO per lane ------------------------------------------------------

@@ -248,35 +248,49 @@ GDW_HD void gdw_reset_tr(WaveLane &L, const WaveK &K, const WaveRow &W)
 // One anti-diagonal for one ACTIVE lane.  pX/pV/pX2: register 7 of X/V/X2 of the previous lane (row r-1 values).
 // bt: the lane's 16 backtrace bytes of this row (4 dwords; byte 4g+h = cell 2g+(h&1)+8*(h>>1)).
 // backtrace byte = (4 - d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6, n* = "no continuation" (inverse of :263-272); bit 7 is undefined.
+// DUAL = false: the single-affine recurrence of ksw_extz2 (K3).  With both gap models equal the second pair (a2, b2) can never
+// win the priority chain (equal value, lower tie code) and its continuation flags are never read by the backtrack, so the whole
+// X2 / Y2 half is dropped; the two flag bits are stored as "no continuation".
+template <bool DUAL = true>
 GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u32 pV, u32 pX2, u32 bt[4])
 {
-	u32 inX = gdw_alignbit(L.X[7], pX, 16), inV = gdw_alignbit(L.V[7], pV, 16), inX2 = gdw_alignbit(L.X2[7], pX2, 16);
+	u32 inX = gdw_alignbit(L.X[7], pX, 16), inV = gdw_alignbit(L.V[7], pV, 16), inX2 = DUAL ? gdw_alignbit(L.X2[7], pX2, 16) : 0u;
 	if (L.blk == W.st_ && !W.use_array) { // first computed block: boundary scalars x1, v1, x21 (:149-159)
 		inX = (inX & 0xffff0000u) | (K.cx & 0xffffu);
 		inV = (inV & 0xffff0000u) | ((u32)W.v1key & 0xffffu);
-		inX2 = (inX2 & 0xffff0000u) | (K.cx2 & 0xffffu);
+		if (DUAL) inX2 = (inX2 & 0xffff0000u) | (K.cx2 & 0xffffu);
 	}
 	u32 zk_hi = 0;
 #pragma unroll
 	for (int k = 7; k >= 0; --k) {
-		const u32 xin = k ? L.X[k - 1] : inX, vin = k ? L.V[k - 1] : inV, x2in = k ? L.X2[k - 1] : inX2;
+		const u32 xin = k ? L.X[k - 1] : inX, vin = k ? L.V[k - 1] : inV, x2in = DUAL ? (k ? L.X2[k - 1] : inX2) : 0u;
 		const u32 sk = gdw_perm(L.Sb[2 + (k >> 2)], L.Sb[k >> 2], 0x0c000c00u | (u32)(k & 3) | (u32)(4 + (k & 3)) << 16);
-		const u32 a = pk_add(xin, vin), b = pk_add(L.Y[k], L.U[k]), a2 = pk_add(x2in, vin), b2 = pk_add(L.Y2[k], L.U[k]);
-		const u32 zk = pk_max(pk_max(pk_max(sk, a), b), pk_add(pk_max(a2, b2), K.c2));
+		const u32 a = pk_add(xin, vin), b = pk_add(L.Y[k], L.U[k]);
+		u32 zk = pk_max(pk_max(sk, a), b), a2 = 0, b2 = 0;
+		if (DUAL) {
+			a2 = pk_add(x2in, vin), b2 = pk_add(L.Y2[k], L.U[k]);
+			zk = pk_max(zk, pk_add(pk_max(a2, b2), K.c2));
+		}
 		const u32 z8 = pk_min(zk & 0xfff8fff8u, K.zmax);
 		const u32 nU = pk_sub(z8, vin), nV = pk_sub(z8, L.U[k]);
-		const u32 tE = pk_sub(z8, K.te), tE2 = pk_sub(z8, K.te2);
+		const u32 tE = pk_sub(z8, K.te);
 		L.X[k] = pk_max(pk_sub(a, tE), K.cx), L.Y[k] = pk_max(pk_sub(b, tE), K.cy);
-		L.X2[k] = pk_max(pk_sub(a2, tE2), K.cx2), L.Y2[k] = pk_max(pk_sub(b2, tE2), K.cy2);
+		if (DUAL) {
+			const u32 tE2 = pk_sub(z8, K.te2);
+			L.X2[k] = pk_max(pk_sub(a2, tE2), K.cx2), L.Y2[k] = pk_max(pk_sub(b2, tE2), K.cy2);
+		}
 		L.U[k] = nU, L.V[k] = nV;
 		if (k & 1) zk_hi = zk;
 		else {
 			// flags of register pairs k (cells k, k+8) and k+1 (cells k+1, k+9) together: the high byte of every 16-bit key
 			// carries its sign = "no continuation"; v_perm gathers them in backtrace byte order
 			const u32 hX = gdw_perm(L.X[k + 1], L.X[k], 0x07030501u), hY = gdw_perm(L.Y[k + 1], L.Y[k], 0x07030501u);
-			const u32 hX2 = gdw_perm(L.X2[k + 1], L.X2[k], 0x07030501u), hY2 = gdw_perm(L.Y2[k + 1], L.Y2[k], 0x07030501u);
-			const u32 f1 = gdw_bfi(0x80808080u, hX, hY >> 1), f2 = gdw_bfi(0x80808080u, hX2, hY2 >> 1);
-			const u32 f = gdw_bfi(0xc0c0c0c0u, f1, f2 >> 2);
+			const u32 f1 = gdw_bfi(0x80808080u, hX, hY >> 1);
+			u32 f;
+			if (DUAL) {
+				const u32 hX2 = gdw_perm(L.X2[k + 1], L.X2[k], 0x07030501u), hY2 = gdw_perm(L.Y2[k + 1], L.Y2[k], 0x07030501u);
+				f = gdw_bfi(0xc0c0c0c0u, f1, gdw_bfi(0x80808080u, hX2, hY2 >> 1) >> 2);
+			} else f = f1 | 0x30303030u;
 			bt[k >> 1] = gdw_bfi(0x78787878u, f >> 1, gdw_perm(zk_hi, zk, 0x06020400u));
 		}
 	}

@@ -96,10 +96,12 @@ int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n,
 /* ---- K3: batched banded SINGLE-affine global alignment -------------------------------------------------------------
  * Replaces ksw_extz2_sse + ksw_backtrack (SR/ksw2_extz2_sse.c:31-312, SR/ksw2.h:62; BASELINE config 2; not called by the live
  * mapping path).  Same batch layout and outputs as gdiet_hip_ksw_extd2_batch; sc->q / sc->e are the gap costs, sc->q2 / sc->e2
- * are ignored, sc->flag must be GDIET_EZ_APPROX_MAX (the only mode GDiet ever passes).  Implementation note: in that mode
- * ksw_extz2(q,e) and ksw_extd2(q,e,q,e) visit identical cells with identical values (the unsigned bias of extz2 is a
- * re-labelling), so the batch runs on the dual-affine kernels with both gap models equal; tests pin this against
- * ksw_extz2_sse's own outputs (tests/golden/ksw2_extz2.npz). */
+ * are ignored, sc->flag must be GDIET_EZ_APPROX_MAX (the only mode GDiet ever passes); sequence bytes must be 0..4 (the one
+ * out-of-alphabet byte GDiet produces, 7 for a reverse-complemented N, only ever reaches ksw_extd2).  Implementation note: in
+ * that mode ksw_extz2(q,e) and ksw_extd2(q,e,q,e) visit identical cells with identical values (the unsigned bias of extz2 is a
+ * re-labelling, and a second gap model equal to the first can never win the priority chain), so the register-resident kernels
+ * run their single-affine form -- the dual-affine recurrence with the X2 / Y2 half dropped -- and the generic LDS kernel runs
+ * with both gap models equal; tests pin this against ksw_extz2_sse's own outputs (tests/golden/ksw2_extz2.npz). */
 int gdiet_hip_ksw_extz2_batch(gdiet_ctx *ctx, int n,
                               const uint8_t *qseq, const int64_t *qoff,
                               const uint8_t *tseq, const int64_t *toff,
