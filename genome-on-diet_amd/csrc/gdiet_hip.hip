@@ -39,6 +39,7 @@ struct gdiet_ctx {
 	hipStream_t stream_dp = nullptr;   // stream of the DP stage in an async lane (GDIET_DP_PRIORITY=1 raises its priority)
 	hipEvent_t ev2[3] = {nullptr, nullptr, nullptr}; // go, DP of the tail done, tail done
 	int dp_split = 1, wave_slots = 5120, last_split = 0;
+	int fuse_bt = 1;                   // GDIET_FUSE_BT=0: the 64-lane kernel leaves the backtrack to the separate kernel
 	bool single_affine = false;        // set for the duration of a gdiet_hip_ksw_extz2_batch call: single-affine kernel variants
 	std::vector<KswTask> h_tasks;
 	std::vector<int32_t> h_ids;
@@ -50,7 +51,9 @@ struct gdiet_ctx {
 	// batches in flight (gdiet_hip_map_submit / _wait): up to GD_MAX_INFLIGHT lane contexts (own stream and scratch) that share THIS
 	// context's backtrace arena, one DP stage at a time
 	gdiet_ctx *parent = nullptr;       // set in an async lane
-	std::mutex dp_mu;                  // serialises the DP stage (and with it the use of the arena) between the lanes
+	std::mutex dp_mu;                  // orders the lanes' DP stages: held while one ENQUEUES its stage behind arena_ev
+	hipEvent_t gather_ev = nullptr;    // this lane's windows are gathered (its DP stream waits for it)
+	hipEvent_t arena_ev = nullptr;     // recorded after the last DP stage that was enqueued: the arena is free once it has completed
 	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool async_busy[4] = {false, false, false, false};
 	int async_next = 0, async_depth = 2;
@@ -134,6 +137,7 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 	}
 	for (int i = 0; i < 3; ++i)
 		if (hipEventCreate(&ctx->ev2[i]) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
+	if (hipEventCreateWithFlags(&ctx->arena_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->gather_ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
 	ctx->wave_slots = prop.multiProcessorCount * 4 * 5; // CUs x SIMDs x resident wavefronts of the 64-lane DP kernel (94 VGPRs)
 	ctx->host_threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 	{
@@ -143,6 +147,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (sl && atoi(sl) > 0) ctx->slices_per_lane = atoi(sl);
 		const char *bw = getenv("GDIET_BT_WAVE");
 		if (bw) ctx->bt_wave = atoi(bw) != 0;
+		const char *fb = getenv("GDIET_FUSE_BT");
+		if (fb) ctx->fuse_bt = atoi(fb) != 0;
 		const char *ds = getenv("GDIET_DP_SPLIT");
 		if (ds) ctx->dp_split = atoi(ds) != 0;
 		const char *sp = getenv("GDIET_SPREAD");
@@ -173,6 +179,8 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 		if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
 	for (int i = 0; i < 3; ++i)
 		if (ctx->ev2[i]) (void)hipEventDestroy(ctx->ev2[i]);
+	if (ctx->arena_ev) (void)hipEventDestroy(ctx->arena_ev);
+	if (ctx->gather_ev) (void)hipEventDestroy(ctx->gather_ev);
 	if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
 	if (ctx->stream_dp) (void)hipStreamDestroy(ctx->stream_dp);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -279,14 +287,14 @@ static int gd_consts(gdiet_ctx *ctx, const gdiet_ksw_score_t *sc, KswConst &K)
 
 // ---- device-pointer entry point ----------------------------------------------------------------------------
 
-extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const int64_t *d_qoff,
-                                             const uint8_t *d_tseq, const int64_t *d_toff, const int32_t *d_w,
-                                             const int32_t *d_exact_score, const gdiet_ksw_score_t *sc,
-                                             int32_t *d_score, int32_t *d_n_cigar, uint32_t *d_cigar,
-                                             const int64_t *d_cigar_off, const int64_t *h_qoff, const int64_t *h_toff,
-                                             const int32_t *h_w, void *stream_)
+// The work of gdiet_hip_ksw_extd2_batch_dev.  h_cigar_off / h_exact_score: host copies of the two small device arrays the
+// planner needs; a caller that has them (the mapping pipeline) passes them and the call then never waits for the stream --
+// which is what lets it be enqueued behind another batch's DP stage.
+static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const uint8_t *d_tseq, const int32_t *d_exact_score,
+                            const gdiet_ksw_score_t *sc, int32_t *d_score, int32_t *d_n_cigar, uint32_t *d_cigar, const int64_t *d_cigar_off,
+                            const int64_t *h_qoff, const int64_t *h_toff, const int32_t *h_w, void *stream_, const int64_t *h_cigar_off,
+                            const int32_t *h_exact_score, hipEvent_t arena_free = nullptr /* the kernels (not the descriptor copies) wait for it */)
 {
-	(void)d_qoff, (void)d_toff, (void)d_w;
 	if (!ctx) return GDIET_E_PARAM;
 	if (n <= 0) return GDIET_OK;
 	if (!d_qseq || !d_tseq || !d_score || !d_n_cigar || !d_cigar || !h_qoff || !h_toff || !h_w) {
@@ -299,14 +307,20 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	int rc = gd_consts(ctx, sc, K);
 	if (rc) return rc;
 	// d_cigar_off / d_exact_score are small: planning needs them on the host
-	std::vector<int64_t> h_cig(n + 1);
-	GD_HIP(hipMemcpyAsync(h_cig.data(), d_cigar_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, stream));
-	std::vector<int32_t> h_ex;
-	if (d_exact_score) {
-		h_ex.resize(n);
-		GD_HIP(hipMemcpyAsync(h_ex.data(), d_exact_score, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream));
+	std::vector<int64_t> h_cig_own;
+	std::vector<int32_t> h_ex_own;
+	if (!h_cigar_off || (d_exact_score && !h_exact_score)) {
+		h_cig_own.resize(n + 1);
+		GD_HIP(hipMemcpyAsync(h_cig_own.data(), d_cigar_off, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, stream));
+		if (d_exact_score) {
+			h_ex_own.resize(n);
+			GD_HIP(hipMemcpyAsync(h_ex_own.data(), d_exact_score, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream));
+		}
+		GD_HIP(hipStreamSynchronize(stream));
+		h_cigar_off = h_cig_own.data(), h_exact_score = d_exact_score ? h_ex_own.data() : nullptr;
 	}
-	GD_HIP(hipStreamSynchronize(stream));
+	const int64_t *h_cig = h_cigar_off;
+	const int32_t *h_ex = h_exact_score;
 
 	ctx->h_tasks.resize(n);
 	const bool wave_scoring_ok = gd_wave_scoring_ok(K);
@@ -377,7 +391,8 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
 	}
 	ctx->last_cells = cells_sum, ctx->last_alg_bytes = alg_sum;
-	DevBuf &arena = ctx->parent ? ctx->parent->arena : ctx->arena; // an async lane works in its parent's arena (under parent->dp_mu)
+	DevBuf &arena = ctx->parent ? ctx->parent->arena : ctx->arena; // an async lane works in its parent's arena (behind parent->arena_ev)
+	if (ctx->parent && bt > arena.cap) GD_HIP(hipEventSynchronize(ctx->parent->arena_ev)); // growing it: the previous user must be done
 	if ((rc = gd_grow(ctx, arena, bt))) return rc;
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * ctx->h_ids.size()))) return rc;
@@ -390,6 +405,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	int32_t *d_status = (int32_t *)ctx->status.p;
 	uint8_t *d_bt = (uint8_t *)arena.p;
 
+	if (arena_free) GD_HIP(hipStreamWaitEvent(stream, arena_free, 0)); // descriptors are across; only the kernels queue behind the arena's last user
 	GD_HIP(hipEventRecord(ctx->ev[0], stream));
 	hipLaunchKernelGGL(ksw_exact_match_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_qseq, d_tseq,
 	                   d_status, d_score, d_n_cigar, d_cigar);
@@ -399,7 +415,8 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	// (shorter, fewer) walks remain after the last DP wavefront.  Same kernels, same work, same results.
 	const int n64 = (int)ids[GD_KIND_WAVE64].size();
 	const bool single = ctx->single_affine && K.q == K.q2 && K.e == K.e2;
-	const bool split = !single && ctx->dp_split && n64 > ctx->wave_slots + ctx->wave_slots / 8;
+	const bool fuse = ctx->fuse_bt != 0; // the 64-lane kernel walks its own alignments back (status TRACED: the kernels below skip them)
+	const bool split = !single && !fuse && ctx->dp_split && n64 > ctx->wave_slots + ctx->wave_slots / 8;
 	const int n_head = split ? ctx->wave_slots : n64;
 	const bool bt_wave = ctx->bt_wave && cells_sum / (uint64_t)n > 200000; // long walks: one wavefront each; short reads: one walk per thread
 	auto backtrack = [&](const int32_t *list, int cnt, hipStream_t st) {
@@ -413,9 +430,11 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 		GD_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev2[0], 0));
 	}
 	if (n64 > 0)
-		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, split ? 1 : 0, single);
+		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, split ? 1 : 0, single,
+		                 fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
 	if (split) {
-		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64] + n_head, n64 - n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, ctx->stream2, 2);
+		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64] + n_head, n64 - n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, ctx->stream2, 2, false,
+		                 fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
 		GD_HIP(hipEventRecord(ctx->ev2[1], ctx->stream2));
 		backtrack(d_ids + id_off[GD_KIND_WAVE64] + n_head, n64 - n_head, ctx->stream2);
 		GD_HIP(hipEventRecord(ctx->ev2[2], ctx->stream2));
@@ -442,6 +461,17 @@ extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_
 	GD_HIP(hipEventRecord(ctx->ev[2], stream));
 	GD_HIP(hipGetLastError());
 	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const int64_t *d_qoff,
+                                             const uint8_t *d_tseq, const int64_t *d_toff, const int32_t *d_w,
+                                             const int32_t *d_exact_score, const gdiet_ksw_score_t *sc,
+                                             int32_t *d_score, int32_t *d_n_cigar, uint32_t *d_cigar,
+                                             const int64_t *d_cigar_off, const int64_t *h_qoff, const int64_t *h_toff,
+                                             const int32_t *h_w, void *stream_)
+{
+	(void)d_qoff, (void)d_toff, (void)d_w;
+	return gd_ksw_batch_dev(ctx, n, d_qseq, d_tseq, d_exact_score, sc, d_score, d_n_cigar, d_cigar, d_cigar_off, h_qoff, h_toff, h_w, stream_, nullptr, nullptr);
 }
 
 extern "C" int gdiet_hip_last_dp_work(const gdiet_ctx *ctx, uint64_t *cells, uint64_t *alg_bytes)

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 	if (tid >= n) return;
 	if (task_ids) { tid = task_ids[tid]; if (tid < 0) return; } // a sub-list of the batch (-1: padding of a 16-lane quartet)
 	const int st = status[tid];
-	if (st == GD_ST_EXACT) return;
+	if (st == GD_ST_EXACT || st == GD_ST_TRACED) return;
 	if (st != GD_ST_DONE) { // band emptied (zdropped): no CIGAR, score stays KSW_NEG_INF (SR/ksw2_extd2_sse.c:142-145,391)
 		n_cigar[tid] = 0;
 		if (st == GD_ST_ZDROPPED) score[tid] = GD_NEG_INF;
@@ -147,26 +147,10 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 // prefetched bytes out of the vector registers with v_readlane.  Same visited cells, same state machine as ksw_backtrack
 // (SR/ksw2.h:131-163); only the latency is hidden differently than in the one-walk-per-thread kernel above, which stays the
 // better choice for short reads (hundreds of thousands of 300-step walks).
-__global__ __launch_bounds__(256) void ksw_backtrack_wave_kernel(const KswTask *__restrict__ tasks, int n,
-                                                                 const uint8_t *__restrict__ bt,
-                                                                 const int32_t *__restrict__ status,
-                                                                 int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
-                                                                 uint32_t *__restrict__ cigar, const int32_t *__restrict__ task_ids)
+// the walk of one alignment by one whole wavefront (all 64 lanes must call it together); writes the CIGAR and n_cigar[tid]
+__device__ __forceinline__ void gd_bt_wave_walk(const KswTask &T, int tid, const uint8_t *__restrict__ bt, int32_t *__restrict__ n_cigar,
+                                                uint32_t *__restrict__ cigar, int lane)
 {
-	const int lane = threadIdx.x & 63;
-	int tid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-	if (tid >= n) return;
-	if (task_ids) { tid = __builtin_amdgcn_readfirstlane(task_ids[tid]); if (tid < 0) return; }
-	const int st = __builtin_amdgcn_readfirstlane(status[tid]);
-	if (st == GD_ST_EXACT) return;
-	if (st != GD_ST_DONE) {
-		if (lane == 0) {
-			n_cigar[tid] = 0;
-			if (st == GD_ST_ZDROPPED) score[tid] = GD_NEG_INF;
-		}
-		return;
-	}
-	const KswTask T = tasks[tid];
 	const int qlen = __builtin_amdgcn_readfirstlane(T.qlen), tlen = __builtin_amdgcn_readfirstlane(T.tlen);
 	const int w0 = __builtin_amdgcn_readfirstlane(T.w);
 	const int w = w0 < 0 ? (tlen > qlen ? tlen : qlen) : w0;
@@ -227,4 +211,26 @@ __global__ __launch_bounds__(256) void ksw_backtrack_wave_kernel(const KswTask *
 			cg[k] = cg[nc - 1 - k], cg[nc - 1 - k] = t0;
 		}
 	}
+}
+
+__global__ __launch_bounds__(256) void ksw_backtrack_wave_kernel(const KswTask *__restrict__ tasks, int n,
+                                                                 const uint8_t *__restrict__ bt,
+                                                                 const int32_t *__restrict__ status,
+                                                                 int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
+                                                                 uint32_t *__restrict__ cigar, const int32_t *__restrict__ task_ids)
+{
+	const int lane = threadIdx.x & 63;
+	int tid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+	if (tid >= n) return;
+	if (task_ids) { tid = __builtin_amdgcn_readfirstlane(task_ids[tid]); if (tid < 0) return; }
+	const int st = __builtin_amdgcn_readfirstlane(status[tid]);
+	if (st == GD_ST_EXACT || st == GD_ST_TRACED) return;
+	if (st != GD_ST_DONE) {
+		if (lane == 0) {
+			n_cigar[tid] = 0;
+			if (st == GD_ST_ZDROPPED) score[tid] = GD_NEG_INF;
+		}
+		return;
+	}
+	gd_bt_wave_walk(tasks[tid], tid, bt, n_cigar, cigar, lane);
 }

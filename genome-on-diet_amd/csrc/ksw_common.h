@@ -34,7 +34,8 @@ struct KswConst {
 };
 
 // per-alignment status written by the kernels
-enum : int32_t { GD_ST_PENDING = 0, GD_ST_EXACT = 1, GD_ST_DONE = 2, GD_ST_ZDROPPED = 3 };
+enum : int32_t { GD_ST_PENDING = 0, GD_ST_EXACT = 1, GD_ST_DONE = 2, GD_ST_ZDROPPED = 3,
+                 GD_ST_TRACED = 4 }; // DP and backtrack both done (the 64-lane kernel walks its own alignment back)
 
 // band of anti-diagonal r (SR/ksw2_extd2_sse.c:138-141); returns st0 > en0 when the band is empty
 static inline __host__ __device__ void gd_band(int r, int qlen, int tlen, int w, int &st0, int &en0)

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
                                                              const uint8_t *__restrict__ qseq,
                                                              const uint8_t *__restrict__ tseq,
                                                              uint8_t *__restrict__ bt, int32_t *__restrict__ status,
-                                                             int32_t *__restrict__ score_out, WaveK K)
+                                                             int32_t *__restrict__ score_out, WaveK K,
+                                                             int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
 {
 	const int lane = threadIdx.x & 63, sub = lane & (LANES - 1), row = LANES == 64 ? 0 : lane >> 4;
 	const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -151,21 +152,29 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 		}
 		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
 	}
+	// The 64-lane form (one alignment per wavefront) walks its own alignment back right away when given the CIGAR buffers: the
+	// walk is latency-bound and overlaps the DP of the other resident wavefronts, instead of a separate pass after the last one.
+	const bool fuse = LANES == 64 && cigar != nullptr;
 	if (L.blk == mlast && live) {
 		score_out[tid] = Rf >> 3;
-		status[tid] = GD_ST_DONE;
+		status[tid] = fuse ? GD_ST_TRACED : GD_ST_DONE;
+	}
+	if (fuse) {
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // this wavefront's own backtrace stores: complete, and not served from a stale L1 line
+		gd_bt_wave_walk(*Tp, tid, bt, n_cigar, cigar, lane);
 	}
 }
 
 static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
-                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int tag = 0, bool single = false)
+                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int tag = 0, bool single = false,
+                                    int32_t *n_cigar = nullptr, uint32_t *cigar = nullptr /* both given: fused backtrack */)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0, false>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
-	else if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
-	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
-	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0, false>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 }
 // ids: 4 task ids per wavefront (identical geometry; -1 pads an incomplete quartet), n_quartets wavefronts
 static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, int n_quartets, const uint8_t *q, const uint8_t *t,
@@ -173,8 +182,8 @@ static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, in
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0, false>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
-	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K);
+	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0, false>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K, (int32_t *)nullptr, (uint32_t *)nullptr);
+	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K, (int32_t *)nullptr, (uint32_t *)nullptr);
 }
 
 // ---- wide bands (ONT, w = 1300): 128 blocks in flight, TWO per lane ------------------------------------------------------

@@ -442,7 +442,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	std::vector<uint32_t> h_cig;
 	std::vector<int64_t> poff(1, 0);
 	// an async lane shares its parent's backtrace arena (two whole-batch arenas do not fit in HBM, and concurrent DP kernels of
-	// smaller batches measured slower): one DP stage (gather .. CIGARs on the host) at a time
+	// smaller batches measured slower): the DP stages take turns
 	std::unique_lock<std::mutex> dp_lock;
 	if (nb > 0) {
 		if ((rc = gd_grow(ctx, ctx->m_boxes, sizeof(MapBox) * nb))) return rc;
@@ -460,21 +460,26 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		gdiet_ksw_score_t ks;
 		ks.match = (int8_t)O.a, ks.mismatch = (int8_t)(O.b < 0 ? O.b : -O.b), ks.sc_ambi = 0, ks.q = (int8_t)O.q, ks.e = (int8_t)O.e, ks.q2 = (int8_t)O.q2, ks.e2 = (int8_t)O.e2;
 		ks.reserved = 0, ks.flag = GDIET_EZ_APPROX_MAX;
-		if (ctx->parent) { // the arena is needed from the DP kernel to the end of the backtrack kernel only
-			GD_HIP(hipStreamSynchronize(s)); // windows gathered: nothing of this lane is queued in front of its DP kernel
-			const double tw = gd_now();
+		// In an async lane the DP stage (pre-filter, DP + backtrack kernels) runs on a stream of its own and is ENQUEUED behind the
+		// DP stage of whichever lane used the shared arena last (arena_ev), so that consecutive DP kernels follow each other on the
+		// GPU without a host round trip in between; dp_mu only orders the enqueueing.
+		hipStream_t sd = s;
+		if (ctx->parent) {
+			sd = ctx->stream_dp;
+			GD_HIP(hipEventRecord(ctx->gather_ev, s)); // windows gathered (and everything else queued on s)
+			GD_HIP(hipStreamWaitEvent(sd, ctx->gather_ev, 0));
 			dp_lock = std::unique_lock<std::mutex>(ctx->parent->dp_mu);
-			ctx->stage_s[5] += gd_now() - tw, t0 += gd_now() - tw; // waiting for the other batch's DP is not this batch's stage time
 		}
-		// in an async lane the DP stage has a stream of its own (everything queued on s is done: the synchronisation above)
-		hipStream_t sd = ctx->parent ? ctx->stream_dp : s;
-		rc = gdiet_hip_ksw_extd2_batch_dev(ctx, nb, (const uint8_t *)ctx->m_q.p, nullptr, (const uint8_t *)ctx->m_t.p, nullptr, nullptr, d_ex, &ks, d_score, d_ncig,
-		                                   (uint32_t *)ctx->m_cig.p, d_coff, qoff.data(), toff.data(), bw.data(), sd);
+		rc = gd_ksw_batch_dev(ctx, nb, (const uint8_t *)ctx->m_q.p, (const uint8_t *)ctx->m_t.p, d_ex, &ks, d_score, d_ncig, (uint32_t *)ctx->m_cig.p, d_coff,
+		                      qoff.data(), toff.data(), bw.data(), sd, coff.data(), ex.data(), ctx->parent ? ctx->parent->arena_ev : nullptr);
 		if (rc) return rc;
+		if (ctx->parent) {
+			GD_HIP(hipEventRecord(ctx->parent->arena_ev, sd)); // the backtrack is done by then: the CIGARs sit in this lane's own buffer
+			dp_lock.unlock();
+		}
 		GD_HIP(hipMemcpyAsync(h_score.data(), d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipMemcpyAsync(h_ncig.data(), d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipStreamSynchronize(sd));
-		if (dp_lock.owns_lock()) dp_lock.unlock(); // backtrack done: the CIGARs sit in this lane's own buffer
 		// CIGARs are short compared with their capacity (qlen+tlen): pack them on the device, then one copy
 		for (int b = 0; b < nb; ++b) if (h_ncig[b] > coff[b + 1] - coff[b]) { ctx->err = "CIGAR capacity exceeded"; return GDIET_E_CIGAR_CAP; }
 		poff.assign(nb + 1, 0);
@@ -560,7 +565,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		gdiet_ctx *c = nullptr;
 		int rc = gdiet_hip_init(&c, ctx->device);
 		if (rc) { ctx->err = "cannot create a pipeline lane"; return rc; }
-		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split;
+		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt;
 		ctx->children.push_back(c);
 	}
 	const int n_slices = std::min(n, lanes * ctx->slices_per_lane);
@@ -635,7 +640,7 @@ extern "C" int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *ix, const
 		ctx->async_lane[l] = c;
 	}
 	gdiet_ctx *c = ctx->async_lane[l];
-	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split;
+	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt;
 	c->lane_threads = c->host_threads = std::max(1, ctx->host_threads / ctx->async_depth);
 	ctx->async_busy[l] = true, ctx->async_next++;
 	t->lane = l;
