@@ -83,6 +83,18 @@ GDW_HD u32 gdw_alignbit(u32 hi, u32 lo, u32 sh) { return (u32)((((uint64_t)hi <<
 GDW_HD u32 gdw_alignbyte(u32 hi, u32 lo, u32 sh) { return (u32)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3))); }
 #endif
 GDW_HD u32 gdw_bfi(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
+// the same with a wave-uniform mask (a constant, or derived from the anti-diagonal index): one v_bfi_b32 with the mask in an SGPR.
+// The compiler splits the C form into v_and + v_and + v_or once the mask is a constant (~mask folds into a second constant).
+#if defined(__HIP_DEVICE_COMPILE__)
+GDW_HD u32 gdw_bfi_u(u32 mask, u32 a, u32 b)
+{
+	u32 d;
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+	return d;
+}
+#else
+GDW_HD u32 gdw_bfi_u(u32 mask, u32 a, u32 b) { return gdw_bfi(mask, a, b); }
+#endif
 GDW_HD u32 gdw_pack2(int v) { return ((u32)v & 0xffffu) | ((u32)v << 16); }
 GDW_HD int gdw_lo(u32 a) { return (int)(int16_t)(a & 0xffffu); }
 GDW_HD int gdw_hi(u32 a) { return (int)(int16_t)(a >> 16); }
@@ -285,13 +297,13 @@ GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u
 			// flags of register pairs k (cells k, k+8) and k+1 (cells k+1, k+9) together: the high byte of every 16-bit key
 			// carries its sign = "no continuation"; v_perm gathers them in backtrace byte order
 			const u32 hX = gdw_perm(L.X[k + 1], L.X[k], 0x07030501u), hY = gdw_perm(L.Y[k + 1], L.Y[k], 0x07030501u);
-			const u32 f1 = gdw_bfi(0x80808080u, hX, hY >> 1);
+			const u32 f1 = gdw_bfi_u(0x80808080u, hX, hY >> 1);
 			u32 f;
 			if (DUAL) {
 				const u32 hX2 = gdw_perm(L.X2[k + 1], L.X2[k], 0x07030501u), hY2 = gdw_perm(L.Y2[k + 1], L.Y2[k], 0x07030501u);
-				f = gdw_bfi(0xc0c0c0c0u, f1, gdw_bfi(0x80808080u, hX2, hY2 >> 1) >> 2);
+				f = gdw_bfi_u(0xc0c0c0c0u, f1, gdw_bfi_u(0x80808080u, hX2, hY2 >> 1) >> 2);
 			} else f = f1 | 0x30303030u;
-			bt[k >> 1] = gdw_bfi(0x78787878u, f >> 1, gdw_perm(zk_hi, zk, 0x06020400u));
+			bt[k >> 1] = gdw_bfi_u(0x78787878u, f >> 1, gdw_perm(zk_hi, zk, 0x06020400u));
 		}
 	}
 }
