@@ -57,6 +57,8 @@ struct gdiet_ctx {
 	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool async_busy[4] = {false, false, false, false};
 	int async_next = 0, async_depth = 2;
+	bool last_was_async = false;       // gdiet_hip_last_kernel_ms then reports the lane's events, copied at gdiet_hip_map_wait
+	float async_dp_ms = 0, async_bt_ms = 0;
 	int map_lanes = 1;                 // software-pipeline depth of gdiet_hip_map_uploaded
 	int slices_per_lane = 1;           // GDIET_SLICES_PER_LANE
 	std::vector<gdiet_ctx *> children; // the lanes (child contexts on the same device)
@@ -485,6 +487,11 @@ extern "C" int gdiet_hip_last_dp_work(const gdiet_ctx *ctx, uint64_t *cells, uin
 extern "C" int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *bt_ms)
 {
 	if (!ctx) return GDIET_E_PARAM;
+	if (ctx->last_was_async) {
+		if (dp_ms) *dp_ms = ctx->async_dp_ms;
+		if (bt_ms) *bt_ms = ctx->async_bt_ms;
+		return GDIET_OK;
+	}
 	float a = 0, b = 0;
 	GD_HIP(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
 	if (ctx->last_split) { // the DP phase ends with the later of the two launches

@@ -541,6 +541,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	GdMapOpt O;
 	gd_opt_from_c(copt, ix, O);
 	{ const int rc = gd_check_opt(ctx, O); if (rc) return rc; }
+	ctx->last_was_async = false;
 	for (int i = 0; i < 4; ++i)
 		if (ctx->async_busy[i]) { ctx->err = "batches submitted with gdiet_hip_map_submit are still in flight"; return GDIET_E_PARAM; }
 
@@ -661,6 +662,10 @@ extern "C" int gdiet_hip_map_wait(gdiet_ctx *ctx, gdiet_map_ticket *t)
 	if (rc) ctx->err = c->err;
 	for (int i = 0; i < 6; ++i) ctx->stage_s[i] = c->stage_s[i];
 	ctx->last_mask = c->last_mask, ctx->last_cells = c->last_cells, ctx->last_alg_bytes = c->last_alg_bytes;
+	if (!rc && c->last_cells) { // the lane's DP-stage events of this batch (its streams are idle: the thread has joined)
+		ctx->last_was_async = false;
+		if (gdiet_hip_last_kernel_ms(c, &ctx->async_dp_ms, &ctx->async_bt_ms) == GDIET_OK) ctx->last_was_async = true;
+	}
 	ctx->async_busy[t->lane] = false;
 	delete t;
 	return rc;
