@@ -165,3 +165,134 @@ static inline void gd_index_build(GdIndex &I, const std::vector<std::string> &na
 	for (int t = 0; t < std::max(1, n_threads); ++t) th.emplace_back(insw);
 	for (auto &t : th) t.join();
 }
+
+// ---- flat form -> GdIndex (what gdiet_hip_index_import and the .mmi reader feed) -------------------------------------------------
+// keys[i] = minimizer hash (x >> 8), cnt[i] its number of occurrences, pos = the occurrence lists (y values, each ascending)
+// concatenated in key order.
+static inline void gd_index_from_flat(GdIndex &h, int k, int w, const GdPattern &P, int n_seq, const char *const *names, const uint32_t *lens,
+                                      const uint64_t *offsets, const uint32_t *S, uint64_t n_keys, const uint64_t *keys, const uint32_t *cnt,
+                                      const uint64_t *pos)
+{
+	h.k = k, h.w = w, h.pat = P;
+	h.seq.resize(n_seq);
+	uint64_t sum = 0;
+	for (int i = 0; i < n_seq; ++i)
+		h.seq[i].name = names && names[i] ? names[i] : "", h.seq[i].len = lens[i], h.seq[i].offset = offsets[i], sum = std::max<uint64_t>(sum, offsets[i] + lens[i]);
+	h.S.assign(S, S + (sum + 7) / 8);
+	h.n_keys = n_keys;
+	h.key_counts.assign(cnt, cnt + n_keys);
+	uint64_t tot = 0;
+	for (uint64_t i = 0; i < n_keys; ++i) tot += cnt[i];
+	h.pos.assign(pos, pos + tot);
+	h.tbits = 4;
+	while ((1ull << h.tbits) < 2 * n_keys + 16) ++h.tbits;
+	h.tkey.assign(1ull << h.tbits, UINT64_MAX), h.tval.assign(1ull << h.tbits, 0);
+	const uint32_t mask = (uint32_t)((1ull << h.tbits) - 1);
+	uint64_t st = 0;
+	for (uint64_t i = 0; i < n_keys; ++i) {
+		uint32_t s = gd_idx_slot(keys[i], h.tbits);
+		while (h.tkey[s] != UINT64_MAX) s = (s + 1) & mask;
+		h.tkey[s] = keys[i], h.tval[s] = st << 32 | cnt[i];
+		st += cnt[i];
+	}
+}
+
+// ---- .mmi files (LR/index.c:480-571: mm_idx_dump / mm_idx_load) -----------------------------------------------------------------
+// Layout: "MMI\2", u32 w,k,b,n_seq,flag; per sequence u8 l, name[l], u32 len; per bucket (1<<b of them) i32 n, u64 p[n],
+// u32 size, size x {u64 key, u64 val}; then u32 S[(sum_len+7)/8].  key = (minimizer >> b) << 1 | singleton, the bucket number is
+// the low b bits of the minimizer; val = the position itself (singleton) or start << 32 | count into p[] (LR/index.c:241-264).
+// The file does not store the pattern (LR/index.c:484-486): -Z / -W must be given again, as with the reference.
+static inline bool gd_index_read_mmi(GdIndex &h, const char *path, const GdPattern &P, std::string &err)
+{
+	FILE *fp = fopen(path, "rb");
+	if (!fp) { err = std::string("cannot open ") + path; return false; }
+	auto fail = [&](const char *why) { fclose(fp); err = std::string(path) + ": " + why; return false; };
+	char magic[4];
+	uint32_t x[5];
+	if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "MMI\2", 4) != 0) return fail("not an MMI\\2 index");
+	if (fread(x, 4, 5, fp) != 5) return fail("truncated header");
+	const uint32_t w = x[0], k = x[1], b = x[2], n_seq = x[3];
+	if (b > 28 || n_seq == 0) return fail("implausible header");
+	std::vector<std::string> names(n_seq);
+	std::vector<uint32_t> lens(n_seq);
+	std::vector<uint64_t> offs(n_seq);
+	uint64_t sum_len = 0;
+	for (uint32_t i = 0; i < n_seq; ++i) {
+		uint8_t l;
+		if (fread(&l, 1, 1, fp) != 1) return fail("truncated sequence table");
+		names[i].resize(l);
+		if (l && fread(&names[i][0], 1, l, fp) != l) return fail("truncated sequence table");
+		if (fread(&lens[i], 4, 1, fp) != 1) return fail("truncated sequence table");
+		offs[i] = sum_len, sum_len += lens[i];
+	}
+	std::vector<uint64_t> keys, pos, p, kv;
+	std::vector<uint32_t> cnt;
+	for (uint64_t bi = 0; bi < (1ull << b); ++bi) {
+		int32_t n;
+		uint32_t size;
+		if (fread(&n, 4, 1, fp) != 1 || n < 0) return fail("truncated bucket");
+		p.resize((size_t)n);
+		if (n && fread(p.data(), 8, (size_t)n, fp) != (size_t)n) return fail("truncated bucket");
+		if (fread(&size, 4, 1, fp) != 1) return fail("truncated bucket");
+		kv.resize(2 * (size_t)size);
+		if (size && fread(kv.data(), 8, 2 * (size_t)size, fp) != 2 * (size_t)size) return fail("truncated bucket");
+		for (uint32_t j = 0; j < size; ++j) {
+			const uint64_t key = kv[2 * j], val = kv[2 * j + 1];
+			keys.push_back((key >> 1) << b | bi);
+			if (key & 1) cnt.push_back(1), pos.push_back(val);
+			else {
+				const uint64_t st = val >> 32, c = (uint32_t)val;
+				if (st + c > (uint64_t)n) return fail("bucket entry out of range");
+				cnt.push_back((uint32_t)c);
+				pos.insert(pos.end(), p.begin() + st, p.begin() + st + c);
+			}
+		}
+	}
+	std::vector<uint32_t> S((sum_len + 7) / 8);
+	if (!S.empty() && fread(S.data(), 4, S.size(), fp) != S.size()) return fail("truncated sequence data (an index written with MM_I_NO_SEQ cannot be used)");
+	fclose(fp);
+	std::vector<const char *> np(n_seq);
+	for (uint32_t i = 0; i < n_seq; ++i) np[i] = names[i].c_str();
+	gd_index_from_flat(h, (int)k, (int)w, P, (int)n_seq, np.data(), lens.data(), offs.data(), S.data(), keys.size(), keys.data(), cnt.data(), pos.data());
+	return true;
+}
+
+// Writes an index the reference's mm_idx_load accepts (same records as mm_idx_dump; the order of the keys inside a bucket is
+// khash-internal in the reference's files and carries no meaning: mm_idx_load re-inserts them one by one).
+static inline bool gd_index_write_mmi(const GdIndex &h, const char *path, int bucket_bits, std::string &err)
+{
+	FILE *fp = fopen(path, "wb");
+	if (!fp) { err = std::string("cannot create ") + path; return false; }
+	const uint32_t b = (uint32_t)bucket_bits;
+	uint32_t x[5] = {(uint32_t)h.w, (uint32_t)h.k, b, (uint32_t)h.seq.size(), 0};
+	fwrite("MMI\2", 1, 4, fp), fwrite(x, 4, 5, fp);
+	uint64_t sum_len = 0;
+	for (const GdSeqInfo &s : h.seq) {
+		const uint8_t l = (uint8_t)std::min<size_t>(s.name.size(), 255);
+		fwrite(&l, 1, 1, fp), fwrite(s.name.data(), 1, l, fp), fwrite(&s.len, 4, 1, fp);
+		sum_len += s.len;
+	}
+	std::vector<std::vector<uint32_t>> slots(1u << b); // table slots by bucket (low b bits of the minimizer)
+	for (size_t sl = 0; sl < h.tkey.size(); ++sl)
+		if (h.tkey[sl] != UINT64_MAX) slots[h.tkey[sl] & ((1u << b) - 1)].push_back((uint32_t)sl);
+	std::vector<uint64_t> p, kv;
+	for (uint32_t bi = 0; bi < (1u << b); ++bi) {
+		p.clear(), kv.clear();
+		for (uint32_t sl : slots[bi]) {
+			const uint64_t st = h.tval[sl] >> 32, c = (uint32_t)h.tval[sl], key = h.tkey[sl] >> b << 1;
+			if (c == 1) kv.push_back(key | 1), kv.push_back(h.pos[st]);
+			else {
+				kv.push_back(key), kv.push_back((uint64_t)p.size() << 32 | c);
+				p.insert(p.end(), h.pos.begin() + st, h.pos.begin() + st + c);
+			}
+		}
+		const int32_t n = (int32_t)p.size();
+		const uint32_t size = (uint32_t)(kv.size() / 2);
+		fwrite(&n, 4, 1, fp), fwrite(p.data(), 8, p.size(), fp), fwrite(&size, 4, 1, fp), fwrite(kv.data(), 8, kv.size(), fp);
+	}
+	fwrite(h.S.data(), 4, (sum_len + 7) / 8, fp);
+	const bool ok = fflush(fp) == 0 && !ferror(fp);
+	fclose(fp);
+	if (!ok) err = std::string("write error on ") + path;
+	return ok;
+}

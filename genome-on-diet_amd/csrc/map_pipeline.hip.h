@@ -133,28 +133,7 @@ extern "C" int gdiet_hip_index_import(gdiet_ctx *ctx, gdiet_index **out, int k, 
 	GdPattern P;
 	if (!gd_pattern_init(P, pattern, pattern_len)) { ctx->err = "bad pattern"; return GDIET_E_PARAM; }
 	gdiet_index *ix = new gdiet_index();
-	GdIndex &h = ix->h;
-	h.k = k, h.w = w, h.pat = P;
-	h.seq.resize(n_seq);
-	uint64_t sum = 0;
-	for (int i = 0; i < n_seq; ++i) h.seq[i].name = names && names[i] ? names[i] : "", h.seq[i].len = lens[i], h.seq[i].offset = offsets[i], sum = std::max<uint64_t>(sum, offsets[i] + lens[i]);
-	h.S.assign(S, S + (sum + 7) / 8);
-	h.n_keys = n_keys;
-	h.key_counts.assign(cnt, cnt + n_keys);
-	uint64_t tot = 0;
-	for (uint64_t i = 0; i < n_keys; ++i) tot += cnt[i];
-	h.pos.assign(pos, pos + tot);
-	h.tbits = 4;
-	while ((1ull << h.tbits) < 2 * n_keys + 16) ++h.tbits;
-	h.tkey.assign(1ull << h.tbits, UINT64_MAX), h.tval.assign(1ull << h.tbits, 0);
-	const uint32_t mask = (uint32_t)((1ull << h.tbits) - 1);
-	uint64_t st = 0;
-	for (uint64_t i = 0; i < n_keys; ++i) {
-		uint32_t s = gd_idx_slot(keys[i], h.tbits);
-		while (h.tkey[s] != UINT64_MAX) s = (s + 1) & mask;
-		h.tkey[s] = keys[i], h.tval[s] = st << 32 | cnt[i];
-		st += cnt[i];
-	}
+	gd_index_from_flat(ix->h, k, w, P, n_seq, names, lens, offsets, S, n_keys, keys, cnt, pos);
 	int rc = gd_index_upload(ctx, ix);
 	if (rc) { delete ix; return rc; }
 	*out = ix;
@@ -187,6 +166,27 @@ extern "C" int gdiet_hip_index_export(const gdiet_index *ix, uint64_t *n_keys, u
 	if (S) memcpy(S, h.S.data(), 4 * h.S.size());
 	if (offsets) for (size_t i = 0; i < h.seq.size(); ++i) offsets[i] = h.seq[i].offset;
 	return GDIET_OK;
+}
+
+// ---- .mmi files: parser / writer in map_index.h (gd_index_read_mmi / gd_index_write_mmi) ---------------------------------------
+extern "C" int gdiet_hip_index_load_mmi(gdiet_ctx *ctx, gdiet_index **out, const char *path, const char *pattern, int pattern_len)
+{
+	if (!ctx || !out || !path) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	GdPattern P;
+	if (!gd_pattern_init(P, pattern, pattern_len)) { ctx->err = "bad pattern"; return GDIET_E_PARAM; }
+	gdiet_index *ix = new gdiet_index();
+	if (!gd_index_read_mmi(ix->h, path, P, ctx->err)) { delete ix; return GDIET_E_PARAM; }
+	int rc = gd_index_upload(ctx, ix);
+	if (rc) { delete ix; return rc; }
+	*out = ix;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_index_dump_mmi(gdiet_ctx *ctx, const gdiet_index *ix, const char *path, int bucket_bits)
+{
+	if (!ctx || !ix || !path || bucket_bits < 1 || bucket_bits > 28) return GDIET_E_PARAM;
+	return gd_index_write_mmi(ix->h, path, bucket_bits, ctx->err) ? GDIET_OK : GDIET_E_PARAM;
 }
 
 extern "C" void gdiet_hip_index_destroy(gdiet_ctx *ctx, gdiet_index *ix)

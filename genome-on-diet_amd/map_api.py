@@ -59,6 +59,8 @@ def _bind(lib):
     lib.gdiet_hip_index_import.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, cpp, u32p, u64p, u32p,
                                            C.c_uint64, u64p, u32p, u64p]
     lib.gdiet_hip_index_export.argtypes = [vp, u64p, u64p, u64p, u64p, u32p, u64p, u32p, u64p]
+    lib.gdiet_hip_index_load_mmi.argtypes = [vp, C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_int]
+    lib.gdiet_hip_index_dump_mmi.argtypes = [vp, vp, C.c_char_p, C.c_int]
     lib.gdiet_hip_index_destroy.argtypes = [vp, vp]
     lib.gdiet_hip_index_destroy.restype = None
     lib.gdiet_hip_index_cal_max_occ.argtypes = [vp, C.c_float]
@@ -154,6 +156,24 @@ class Mapper:
         ctx._check(rc)
         self._setup_opt()
         return self
+
+    @classmethod
+    def from_mmi(cls, ctx, path, names, lens, preset="hifi", **overrides):
+        """gdiet_hip_index_load_mmi: an index file written by the reference (`GDiet -d`)"""
+        self = cls.__new__(cls)
+        self.ctx, self.lib = ctx, load_library()
+        _bind(self.lib)
+        p = dict(PRESETS[preset])
+        p.update(overrides)
+        self.p = p
+        self.names, self.lens = list(names), np.ascontiguousarray(lens, np.uint32)
+        self._idx = C.c_void_p()
+        ctx._check(self.lib.gdiet_hip_index_load_mmi(ctx._h, C.byref(self._idx), path.encode(), p["Z"].encode(), p["W"]))
+        self._setup_opt()
+        return self
+
+    def dump_mmi(self, path, bucket_bits=14):
+        self.ctx._check(self.lib.gdiet_hip_index_dump_mmi(self.ctx._h, self._idx, path.encode(), bucket_bits))
 
     def export_index(self):
         u64, u32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)

@@ -60,6 +60,7 @@ int main(int argc, char **argv)
 	int W = 2;
 	O.flag = GD_F_NO_PRINT_2ND * 0;
 	std::vector<const char *> pos;
+	const char *mmi_in = nullptr, *mmi_out = nullptr;
 	bool preset_seen = false, sr_variant = false;
 	auto preset = [&](const char *p) -> bool {
 		if (!strcmp(p, "map-hifi")) { O.k = 19, O.w = 19, O.a = 1, O.b = 4, O.q = 6, O.q2 = 26, O.e = 2, O.e2 = 1, O.occ_dist = 500, min_mid_occ = 50, max_mid_occ = 500; }
@@ -117,6 +118,8 @@ int main(int argc, char **argv)
 				if (pass) { char *e; O.min_cnt = strtof(v, &e); if (*e == ',') O.rec_threshold_frac = strtof(e + 1, &e); }
 			}
 			else if ((v = val("AF_max_loc"))) { if (pass) O.af_max_loc = (int)atof(v); }
+			else if ((v = val("mmi"))) { if (pass) mmi_in = v; }           // use an .mmi written by the reference instead of building the index
+			else if ((v = val("dump-mmi"))) { if (pass) mmi_out = v; }    // write the index as an .mmi and exit
 			else if (a == "-s") { v = argv[++i]; if (pass) O.min_dp_max = atoi(v); }
 			else if (a == "-N") { v = argv[++i]; if (pass) O.best_n = atoi(v); }
 			else if (a.compare(0, 2, "-F") == 0) { if (a.size() == 2) ++i; }
@@ -148,7 +151,15 @@ int main(int argc, char **argv)
 	GdIndex I;
 	std::vector<GdSeqSpan> spans(rs.size());
 	for (size_t i = 0; i < rs.size(); ++i) spans[i].p = rs[i].data(), spans[i].n = rs[i].size();
-	gd_index_build(I, rn, spans, O.k, O.w, O.pat, 8, true);
+	if (mmi_in) {
+		std::string err;
+		if (!gd_index_read_mmi(I, mmi_in, O.pat, err)) { fprintf(stderr, "%s\n", err.c_str()); return 2; }
+	} else gd_index_build(I, rn, spans, O.k, O.w, O.pat, 8, true);
+	if (mmi_out) {
+		std::string err;
+		if (!gd_index_write_mmi(I, mmi_out, 14, err)) { fprintf(stderr, "%s\n", err.c_str()); return 2; }
+		return 0;
+	}
 	// mm_mapopt_update (LR/options.c:64-76)
 	if (O.mid_occ <= 0) {
 		O.mid_occ = gd_index_cal_max_occ(I, mid_occ_frac);

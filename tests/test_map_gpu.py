@@ -117,3 +117,36 @@ def test_two_batches_in_flight_give_the_same_records(gpu_ctx, pkg):
         m.free_batch(bb)
     finally:
         m.close()
+
+
+def test_mmi_index_files(gpu_ctx, pkg, tmp_path):
+    """gdiet_hip_index_load_mmi on an index file written by the reference itself (`GDiet_avx -ax sr ... -d`, committed under
+    tests/golden/sr) gives the golden SAM; gdiet_hip_index_dump_mmi -> load_mmi round-trips"""
+    import gzip
+    import shutil
+    from fixture_io import SR
+    names, seqs = read_fasta(os.path.join(SR, "ref.fa.gz"))
+    reads = reads_of("sr")[:600]
+    want = [l for l in golden_sam("sr") if l.split("\t")[0] in {r[0] for r in reads}]
+    theirs = str(tmp_path / "theirs.mmi")
+    with gzip.open(os.path.join(SR, "ref.k21w11.mmi.gz"), "rb") as src, open(theirs, "wb") as dst:
+        shutil.copyfileobj(src, dst)
+
+    def run(m):
+        res = m.map([r[1] for r in reads])
+        return [line for i, (qn, sq, ql) in enumerate(reads) for line in m.sam(res, i, qn, sq, ql)]
+
+    m = pkg.Mapper.from_mmi(gpu_ctx, theirs, names, [len(s) for s in seqs], preset="sr")
+    try:
+        assert run(m) == want
+        ours = str(tmp_path / "ours.mmi")
+        m.dump_mmi(ours)
+        m2 = pkg.Mapper.from_mmi(gpu_ctx, ours, names, [len(s) for s in seqs], preset="sr")
+        try:
+            assert m2.n_keys() == m.n_keys() and run(m2) == want
+        finally:
+            m2.close()
+    finally:
+        m.close()
+    with pytest.raises(pkg.GdietError):
+        pkg.Mapper.from_mmi(gpu_ctx, os.path.join(SR, "sr.cmd"), names, [len(s) for s in seqs], preset="sr")  # not an index file

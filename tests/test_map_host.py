@@ -85,3 +85,30 @@ def test_sr_host_path_matches_reference_binary_on_fresh_reads(host_driver, tmp_p
     want = [l for l in want.rstrip("\n").split("\n") if not l.startswith("@")]
     got = subprocess.run([exe] + cmd + [ref_fa, fq], capture_output=True, text=True, check=True).stdout.rstrip("\n").split("\n")
     assert got == want
+
+
+@pytest.mark.parametrize("kind", ["hifi", "sr"])
+def test_mmi_files_are_exchangeable_with_the_reference(host_driver, tmp_path, kind):
+    """the .mmi reader / writer behind gdiet_hip_index_load_mmi / _dump_mmi (map_index.h): (1) an index file written by the
+    reference (`GDiet_avx -d`) gives the golden SAM through our path; (2) an index file written by us is accepted by the
+    reference and gives the golden SAM through ITS path"""
+    variant = "sr" if kind == "sr" else "lr"
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "gdiet_%s_avx" % variant)
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    exe, d = host_driver
+    ref_fa = os.path.join(d, variant, "ref.fa")
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for name, seq, qual in reads_of(kind)[:400]:
+            f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
+    cmd = cmd_of(kind)
+    want = subprocess.run([ref_bin, "-t", "4"] + cmd + [ref_fa, fq], capture_output=True, text=True, check=True).stdout
+    want = [l for l in want.rstrip("\n").split("\n") if not l.startswith("@")]
+    theirs, ours = str(tmp_path / "theirs.mmi"), str(tmp_path / "ours.mmi")
+    subprocess.run([ref_bin, "-t", "4"] + cmd + ["-d", theirs, ref_fa], capture_output=True, check=True)
+    got = subprocess.run([exe] + cmd + ["--mmi=" + theirs, ref_fa, fq], capture_output=True, text=True, check=True).stdout.rstrip("\n").split("\n")
+    assert got == want
+    subprocess.run([exe] + cmd + ["--dump-mmi=" + ours, ref_fa, fq], capture_output=True, check=True)
+    back = subprocess.run([ref_bin, "-t", "4"] + cmd + [ours, fq], capture_output=True, text=True, check=True).stdout
+    assert [l for l in back.rstrip("\n").split("\n") if not l.startswith("@")] == want
