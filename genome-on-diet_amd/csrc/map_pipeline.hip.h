@@ -16,6 +16,10 @@ struct gdiet_index {
 	GdIndex h;
 	void *d_tkey = nullptr, *d_tval = nullptr, *d_pos = nullptr, *d_S = nullptr;
 	GdIdxView dview;
+	// device-built index (map_index_dev.hip.h): the table exists on the device only until someone asks for the host copies
+	bool host_tables = true;
+	uint32_t *d_cnt_sorted = nullptr; // occurrence counts of the keys, ascending (mm_idx_cal_max_occ)
+	uint64_t n_pos = 0;
 };
 
 struct gdiet_read_batch {
@@ -24,6 +28,8 @@ struct gdiet_read_batch {
 	std::vector<uint8_t> enc;           // nt4, forward strand, all reads packed (host copy for post-processing)
 	void *d_reads = nullptr, *d_roff = nullptr;
 };
+
+#include "map_index_dev.hip.h"
 
 // Persistent host worker pool (one per context): the host stages of a batch are a few hundred microseconds of work per
 // thread, so creating the threads per call (tens of microseconds EACH, serialised) used to cost more than the work.
@@ -117,7 +123,13 @@ extern "C" int gdiet_hip_index_build(gdiet_ctx *ctx, gdiet_index **out, int n_se
 	std::vector<std::string> nm(n_seq);
 	std::vector<GdSeqSpan> sq(n_seq);
 	for (int i = 0; i < n_seq; ++i) nm[i] = names && names[i] ? names[i] : "", sq[i].p = seqs[i], sq[i].n = lens[i];
-	gd_index_build(ix->h, nm, sq, k, w, P, n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency(), true);
+	const int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+	if (ctx->index_on_device) { // sketch, sort and table build on the GPU (map_index_dev.hip.h); GDIET_INDEX_BUILD=host selects the host builder
+		if (!gd_index_build_device(ix, nm, sq, k, w, P, nt, ctx->stream, ctx->err)) { gdiet_hip_index_destroy(ctx, ix); return GDIET_E_HIP; }
+		*out = ix;
+		return GDIET_OK;
+	}
+	gd_index_build(ix->h, nm, sq, k, w, P, nt, true);
 	int rc = gd_index_upload(ctx, ix);
 	if (rc) { delete ix; return rc; }
 	*out = ix;
@@ -145,6 +157,7 @@ extern "C" int gdiet_hip_index_export(const gdiet_index *ix, uint64_t *n_keys, u
                                       uint32_t *cnt, uint64_t *pos, uint32_t *S, uint64_t *offsets)
 {
 	if (!ix) return GDIET_E_PARAM;
+	{ std::string e; if (!gd_index_fetch_host(const_cast<gdiet_index *>(ix), e)) return GDIET_E_HIP; }
 	const GdIndex &h = ix->h;
 	if (n_keys) *n_keys = h.n_keys;
 	if (n_pos) *n_pos = h.pos.size();
@@ -186,6 +199,7 @@ extern "C" int gdiet_hip_index_load_mmi(gdiet_ctx *ctx, gdiet_index **out, const
 extern "C" int gdiet_hip_index_dump_mmi(gdiet_ctx *ctx, const gdiet_index *ix, const char *path, int bucket_bits)
 {
 	if (!ctx || !ix || !path || bucket_bits < 1 || bucket_bits > 28) return GDIET_E_PARAM;
+	if (!gd_index_fetch_host(const_cast<gdiet_index *>(ix), ctx->err)) return GDIET_E_HIP;
 	return gd_index_write_mmi(ix->h, path, bucket_bits, ctx->err) ? GDIET_OK : GDIET_E_PARAM;
 }
 
@@ -193,12 +207,25 @@ extern "C" void gdiet_hip_index_destroy(gdiet_ctx *ctx, gdiet_index *ix)
 {
 	if (!ix) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
-	void *p[] = {ix->d_tkey, ix->d_tval, ix->d_pos, ix->d_S};
+	void *p[] = {ix->d_tkey, ix->d_tval, ix->d_pos, ix->d_S, ix->d_cnt_sorted};
 	for (void *q : p) if (q) (void)hipFree(q);
 	delete ix;
 }
 
-extern "C" int32_t gdiet_hip_index_cal_max_occ(const gdiet_index *ix, float frac) { return ix ? gd_index_cal_max_occ(ix->h, frac) : 0; }
+extern "C" int32_t gdiet_hip_index_cal_max_occ(const gdiet_index *ix, float frac)
+{
+	if (!ix) return 0;
+	if (ix->host_tables) return gd_index_cal_max_occ(ix->h, frac);
+	// device-built: the counts are on the device, sorted; mm_idx_cal_max_occ (LR/index.c:190-210) is their (1-f) quantile + 1
+	if (frac <= 0.) return INT32_MAX;
+	const size_t n = ix->h.n_keys;
+	if (n == 0) return 1;
+	size_t kk = (size_t)(uint32_t)((1. - frac) * n);
+	if (kk >= n) kk = n - 1;
+	uint32_t v = 0;
+	if (hipMemcpy(&v, ix->d_cnt_sorted + kk, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+	return (int32_t)(v + 1);
+}
 extern "C" uint64_t gdiet_hip_index_n_keys(const gdiet_index *ix) { return ix ? ix->h.n_keys : 0; }
 
 extern "C" int gdiet_hip_set_host_threads(gdiet_ctx *ctx, int n)

@@ -150,3 +150,31 @@ def test_mmi_index_files(gpu_ctx, pkg, tmp_path):
         m.close()
     with pytest.raises(pkg.GdietError):
         pkg.Mapper.from_mmi(gpu_ctx, os.path.join(SR, "sr.cmd"), names, [len(s) for s in seqs], preset="sr")  # not an index file
+
+
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr"])
+def test_device_built_index_equals_host_built(gpu_ctx, pkg, kind, monkeypatch):
+    """gdiet_hip_index_build on the device (sketch slices, radix sorts, run-length encode, CAS table) against the host builder:
+    same keys, same counts, same position lists in the same order, same mid_occ"""
+    import numpy as np
+    base, stem, preset = SETS[kind]
+    names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+
+    def flat(env):
+        monkeypatch.setenv("GDIET_INDEX_BUILD", env)
+        ctx = pkg.Context(0)  # the builder is chosen when the context is created
+        m = pkg.Mapper(ctx, names, seqs, preset=preset)
+        try:
+            f = m.export_index()
+            order = np.argsort(f["keys"], kind="stable")
+            start = np.concatenate([[0], np.cumsum(f["cnt"].astype(np.int64))])
+            pos = np.concatenate([f["pos"][start[j]:start[j + 1]] for j in order]) if len(order) else f["pos"]
+            return f["keys"][order], f["cnt"][order], pos, f["S"], m.mid_occ, m.n_keys()
+        finally:
+            m.close()
+            ctx.close()
+
+    h, d = flat("host"), flat("device")
+    assert h[5] == d[5] and h[4] == d[4]
+    for a, b in zip(h[:4], d[:4]):
+        assert np.array_equal(a, b)
