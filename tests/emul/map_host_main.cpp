@@ -61,6 +61,7 @@ int main(int argc, char **argv)
 	O.flag = GD_F_NO_PRINT_2ND * 0;
 	std::vector<const char *> pos;
 	const char *mmi_in = nullptr, *mmi_out = nullptr;
+	bool trace = false;
 	bool preset_seen = false, sr_variant = false;
 	auto preset = [&](const char *p) -> bool {
 		if (!strcmp(p, "map-hifi")) { O.k = 19, O.w = 19, O.a = 1, O.b = 4, O.q = 6, O.q2 = 26, O.e = 2, O.e2 = 1, O.occ_dist = 500, min_mid_occ = 50, max_mid_occ = 500; }
@@ -118,6 +119,7 @@ int main(int argc, char **argv)
 				if (pass) { char *e; O.min_cnt = strtof(v, &e); if (*e == ',') O.rec_threshold_frac = strtof(e + 1, &e); }
 			}
 			else if ((v = val("AF_max_loc"))) { if (pass) O.af_max_loc = (int)atof(v); }
+			else if (a == "--print-seeds") { if (pass) trace = true; }   // the reference's stage trace (RS/SD/VT/AVT/BE/AL_SCORE lines, LR/map.c:1328-1338,1447-1459,1592-1602,1670-1675,1808-1810)
 			else if ((v = val("mmi"))) { if (pass) mmi_in = v; }           // use an .mmi written by the reference instead of building the index
 			else if ((v = val("dump-mmi"))) { if (pass) mmi_out = v; }    // write the index as an .mmi and exit
 			else if (a == "-s") { v = argv[++i]; if (pass) O.min_dp_max = atoi(v); }
@@ -187,6 +189,7 @@ int main(int argc, char **argv)
 			unsigned tot = gd_sketch2(enc.data(), len, O.w, O.k, O.pat, O.max_seeds, mv.data(), maxm, shift_n.data());
 			(void)tot;
 			const int shift = (int)gd_get_shift(V, mv.data(), shift_n.data(), O.pat.W);
+			if (trace) fprintf(stderr, "QR\t%s\nFinal shift: %d\n", qn[ri].c_str(), shift);
 			unsigned n_mv = 0;
 			const uint32_t cap = (O.flag & GD_F_FRAG_MODE) ? (O.max_frag_len == 0 ? 800u : (uint32_t)O.max_frag_len) : UINT32_MAX;
 			const unsigned tel = gd_sketch3(enc.data(), (unsigned)len, O.w, O.k, O.pat, shift, cap, mv.data(), maxm, &n_mv);
@@ -202,17 +205,47 @@ int main(int argc, char **argv)
 			std::vector<GdLoc> sfv(sf, sf + nf);
 			GdLoc *sr = gd_sort_locs(ar.data(), tmp.data(), nr);
 			std::vector<GdLoc> srv(sr, sr + nr);
+			if (trace) {
+				fprintf(stderr, "RS n_a_for: %u, n_a_rev: %u\n", nf, nr);
+				for (unsigned i = 0; i < nf; ++i) fprintf(stderr, "SD\t%s\t%d\t+\t%u\n", R.seq[sfv[i].target >> 32].name.c_str(), (int32_t)sfv[i].target + 1 - (int32_t)tel, sfv[i].query);
+				for (unsigned i = 0; i < nr; ++i) fprintf(stderr, "SD\t%s\t%d\t-\t%u\n", R.seq[srv[i].target >> 32].name.c_str(), (uint32_t)srv[i].target + 1, srv[i].query);
+			}
 			GdLrVoteOpt VO = {O.vt_dis, O.vt_nb_loc, O.bw, O.vt_cov, O.vt_f, O.vt_df1, O.vt_df2, O.k};
 			GdSrVoteOpt SO = {O.min_cnt, O.rec_threshold_frac, O.bw_frac, O.bw_min, O.bw_max, O.af_max_loc, cap, (O.flag & GD_F_FRAG_MODE) != 0};
 			GdVt vts[GDM_MAX_VT];
 			unsigned nc = sr_variant ? gd_sr_candidates(sfv.data(), nf, srv.data(), nr, (uint32_t)len, tel, n_mv, SO, vts)
 			                         : gd_lr_candidates(sfv.data(), nf, srv.data(), nr, (uint32_t)len, (int32_t)tel, VO, vts);
 			const int dp_bw = sr_variant ? (int)gd_sr_bw(len, SO) : (int)O.bw;
+			if (trace && nc > 0) {
+				fprintf(stderr, "VT n: %u, len: %u\n", nc, (unsigned)len);
+				for (unsigned i = 0; i < nc; ++i) {
+					const GdVt &p = vts[i];
+					if (sr_variant) { // SR/map.c:701-716
+						int32_t pos = p.first_target_loc + 1;
+						if (p.str) pos -= (len - 1);
+						fprintf(stderr, "VT\t%s (len: %u)\t%d\t%c\t[%u, %u]\t%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, pos, "+-"[p.str], p.first_query_loc, p.last_query_loc, p.score);
+					} else
+						fprintf(stderr, "VT\t%s (len: %u)\t[%u, %u]\t%c\t[%u, %u]\t%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, (uint32_t)p.first_target_loc,
+						        (uint32_t)p.last_target_loc, "+-"[p.str], p.first_query_loc, p.last_query_loc, p.score);
+				}
+			}
 			if (nc > 0) {
 				std::vector<GdCand> C(nc);
 				for (unsigned i = 0; i < nc; ++i) C[i].v = vts[i];
 				if (sr_variant) gd_sr_boxes(C, O, R, (uint32_t)len), nc = (unsigned)C.size();
 				else gd_lr_link_and_boxes(C, O, R, (uint32_t)len);
+				if (trace && !sr_variant) {
+					fprintf(stderr, "AVT n: %u, len: %u\n", nc, (unsigned)len);
+					for (unsigned i = 0; i < nc; ++i) {
+						const GdVt &p = C[i].v;
+						fprintf(stderr, "AVT\t%s (len: %u)\t[%u, %u]\t%c\t[%u, %u]\t%u\tc:%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, (uint32_t)p.first_target_loc,
+						        (uint32_t)p.last_target_loc, "+-"[p.str], p.first_query_loc, p.last_query_loc, p.score, (unsigned)C[i].concat);
+					}
+					for (unsigned i = 0; i < nc; ++i)
+						fprintf(stderr, "BE\t%s, [%u, %u[ (chrom_len: %u) -> '%c' [%u, %u[ (read_len: %u)\n", R.seq[C[i].target_id].name.c_str(), C[i].target_start, C[i].target_end,
+						        R.seq[C[i].target_id].len, "+-"[C[i].v.str], // the reference prints the box of a '-' candidate before flipping it to read coordinates
+						        C[i].v.str ? (unsigned)len - 1 - C[i].query_end : C[i].query_start, C[i].v.str ? (unsigned)len - 1 - C[i].query_start : C[i].query_end, (unsigned)len);
+				}
 				std::vector<GdDpResult> dp(nc);
 				std::vector<gdo_extz_t> ez(nc);
 				std::vector<uint32_t> one(nc);
@@ -229,6 +262,7 @@ int main(int argc, char **argv)
 						gdo_ksw_extd2((int)c.qlen, q, (int)c.tlen, t.data(), 5, mat, (int8_t)O.q, (int8_t)O.e, (int8_t)O.q2, (int8_t)O.e2, dp_bw, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez[i]);
 						dp[i] = {ez[i].score, ez[i].cigar, ez[i].n_cigar};
 					}
+					if (trace && !sr_variant) fprintf(stderr, "AL_SCORE: %d\n", dp[i].score);
 				}
 				if (sr_variant) gd_sr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs);
 				else gd_lr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs);

@@ -112,3 +112,41 @@ def test_mmi_files_are_exchangeable_with_the_reference(host_driver, tmp_path, ki
     subprocess.run([exe] + cmd + ["--dump-mmi=" + ours, ref_fa, fq], capture_output=True, check=True)
     back = subprocess.run([ref_bin, "-t", "4"] + cmd + [ours, fq], capture_output=True, text=True, check=True).stdout
     assert [l for l in back.rstrip("\n").split("\n") if not l.startswith("@")] == want
+
+
+@pytest.mark.parametrize("kind,n_reads", [("hifi", 12), ("ont", 6), ("sr", 400)])
+def test_stage_trace_matches_the_reference(host_driver, tmp_path, kind, n_reads):
+    """stage-level parity (the reference's --print-seeds trace): chosen pattern phase, sorted seed hits of both
+    strands, vote candidates before and after linking, DP boxes and DP scores, line for line.  Hits with equal targets may be
+    ordered differently by the two sorts, so the SD lines are compared as a multiset per read."""
+    variant = "sr" if kind == "sr" else "lr"
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "gdiet_%s_avx" % variant)
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    exe, d = host_driver
+    ref_fa = os.path.join(d, variant, "ref.fa")
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for name, seq, qual in reads_of(kind)[:n_reads]:
+            f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
+
+    def trace(binary):
+        err = subprocess.run([binary] + cmd_of(kind) + ["--print-seeds", ref_fa, fq], capture_output=True, text=True, check=True).stderr
+        per_read, cur = [], None
+        for line in err.split("\n"):
+            if line.startswith("Final shift"):
+                cur = {"shift": line, "RS": [], "SD": [], "VT": [], "AVT": [], "BE": [], "AL": []}
+                per_read.append(cur)
+            elif cur is not None:
+                for key, prefix in (("RS", "RS "), ("SD", "SD\t"), ("VT", "VT\t"), ("AVT", "AVT\t"), ("BE", "BE\t"), ("AL", "AL_SCORE")):
+                    if line.startswith(prefix):
+                        cur[key].append(line)
+        for r in per_read:
+            r["SD"].sort()
+        return per_read
+
+    want, got = trace(ref_bin), trace(exe)
+    assert len(want) == len(got) == n_reads
+    for a, b in zip(want, got):
+        assert a == b
+    assert sum(len(r["SD"]) for r in want) > 100 and sum(len(r["VT"]) for r in want) > 0
