@@ -726,3 +726,47 @@ extern "C" size_t gdiet_hip_sam_record(const gdiet_index *ix, const char *qname,
 	if (buf && cap) { const size_t m = std::min(cap - 1, s.size()); memcpy(buf, s.data(), m); buf[m] = 0; }
 	return s.size();
 }
+
+// All SAM records of a batch, in input order, formatted on the context's host threads (step 2 of the reference's pipeline prints
+// them one read at a time on one thread: LR/map.c:2139-2170 -> mm_write_sam3).  A read without alignments gives its unmapped
+// record; with MM_F_NO_PRINT_2ND secondary records are skipped, exactly as the reference's output loop does.
+extern "C" size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *ix, int n_reads, const char *const *qnames, const char *const *seqs,
+                                      const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
+                                      int64_t opt_flag, char **out)
+{
+	if (!ctx || !ix || n_reads < 0 || !qnames || !seqs || !lens || !n_regs || !regs || !out) return 0;
+	*out = nullptr;
+	std::vector<std::string> rec((size_t)n_reads);
+	gd_parallel_for(ctx, ctx->host_threads, n_reads, [&](int i) {
+		const int nr = n_regs[i];
+		std::vector<GdReg> v(nr > 0 ? nr : 0);
+		for (int j = 0; j < nr; ++j) {
+			const gdiet_reg_t &r = regs[i][j];
+			GdReg &g = v[j];
+			g.id = r.id, g.cnt = r.cnt, g.rid = r.rid, g.score = r.score, g.qs = r.qs, g.qe = r.qe, g.rs = r.rs, g.re = r.re, g.parent = r.parent, g.subsc = r.subsc;
+			g.mlen = r.mlen, g.blen = r.blen, g.mapq = r.mapq, g.rev = r.rev, g.sam_pri = r.sam_pri, g.dp_score = r.dp_score, g.dp_max = r.dp_max, g.n_ambi = r.n_ambi;
+			g.has_p = true, g.cigar.assign(r.cigar, r.cigar + r.n_cigar);
+		}
+		std::string &s = rec[i], one;
+		const char *q = quals ? quals[i] : nullptr;
+		if (nr <= 0) {
+			gd_write_sam(one, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, -1, opt_flag);
+			s += one, s += '\n';
+		} else
+			for (int j = 0; j < nr; ++j) {
+				if ((opt_flag & GD_F_NO_PRINT_2ND) && v[j].id != v[j].parent) continue;
+				one.clear();
+				gd_write_sam(one, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, j, opt_flag);
+				s += one, s += '\n';
+			}
+	});
+	size_t tot = 0;
+	for (auto &r : rec) tot += r.size();
+	char *buf = (char *)malloc(tot + 1);
+	if (!buf) return 0;
+	size_t o = 0;
+	for (auto &r : rec) memcpy(buf + o, r.data(), r.size()), o += r.size();
+	buf[tot] = 0;
+	*out = buf;
+	return tot;
+}

@@ -83,6 +83,8 @@ def _bind(lib):
     lib.gdiet_hip_sam_record.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(Reg), C.c_int32, C.c_int32,
                                          C.c_int64, C.c_char_p, C.c_size_t]
     lib.gdiet_hip_sam_record.restype = C.c_size_t
+    lib.gdiet_hip_sam_batch.argtypes = [vp, vp, C.c_int, cpp, cpp, cpp, i32p, i32p, C.POINTER(C.POINTER(Reg)), C.c_int64, C.POINTER(vp)]
+    lib.gdiet_hip_sam_batch.restype = C.c_size_t
     lib._map_bound = True
 
 
@@ -268,6 +270,23 @@ class Mapper:
         out = (C.c_double * 6)()
         self.lib.gdiet_hip_map_stage_seconds(self.ctx._h, out)
         return list(out)
+
+    def sam_batch(self, res, reads):
+        """every SAM record of a MapResult as one string (gdiet_hip_sam_batch); reads = [(qname, seq, qual or None), ...]"""
+        n = len(reads)
+        enc = lambda x: x if isinstance(x, bytes) else x.encode()
+        qn = (C.c_char_p * n)(*[enc(r[0]) for r in reads])
+        sq = (C.c_char_p * n)(*[enc(r[1]) for r in reads])
+        ql = (C.c_char_p * n)(*[None if len(r) < 3 or r[2] is None else enc(r[2]) for r in reads])
+        lens = np.array([len(r[1]) for r in reads], np.int32)
+        out = C.c_void_p()
+        m = self.lib.gdiet_hip_sam_batch(self.ctx._h, self._idx, n, qn, sq, ql, lens.ctypes.data_as(C.POINTER(C.c_int32)), res.n_regs, res.regs,
+                                         self.opt.flag, C.byref(out))
+        try:
+            return C.string_at(out.value, m).decode() if out.value else ""
+        finally:
+            if out.value:
+                C.CDLL(None).free(C.c_void_p(out.value))
 
     def sam(self, res, i, qname, seq, qual=None):
         """SAM lines of read i of a MapResult, as the reference's output step prints them (map.c step 2)."""

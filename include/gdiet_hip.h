@@ -235,6 +235,13 @@ int gdiet_hip_set_host_threads(gdiet_ctx *ctx, int n);
 size_t gdiet_hip_sam_record(const gdiet_index *idx, const char *qname, const char *seq, const char *qual, int32_t l_seq,
                             const gdiet_reg_t *regs, int32_t n_regs, int32_t reg_idx, int64_t opt_flag, char *buf, size_t cap);
 
+/* All records of a batch, in input order, one per line (the body of a SAM file without the header), formatted on the context's
+ * host threads -- step 2 of worker_pipeline (LR/map.c:2139-2170) for a whole mini-batch.  *out is malloc'd (free() it); returns
+ * its length.  quals may be NULL, and so may its entries. */
+size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *idx, int n_reads, const char *const *qnames, const char *const *seqs,
+                           const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
+                           int64_t opt_flag, char **out);
+
 #ifdef __cplusplus
 }
 #endif

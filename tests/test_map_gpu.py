@@ -25,6 +25,7 @@ def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert a == b, (a[:300], b[:300])
+        assert m.sam_batch(res, reads) == "".join(l + "\n" for l in want)  # the batch formatter (host threads) prints the same bytes
         # every DP of the HiFi fixture must have gone through the register-resident kernel
         if kind == "hifi":
             assert gpu_ctx.last_kernel_mask() & 1
