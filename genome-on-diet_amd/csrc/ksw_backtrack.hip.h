@@ -22,6 +22,13 @@ __device__ __forceinline__ size_t gd_bt_index(const KswTask &T, int r, int i, in
 	return (size_t)r * T.row_bytes + (size_t)(bpos << 4) + (g << 2) + h;
 }
 
+// byte of the register-resident kernels -> the reference's backtrace byte
+static inline __host__ __device__ uint32_t gd_bt_decode(uint32_t b)
+{
+	const uint32_t nb = ~b;
+	return (4u - (b & 7u)) | ((nb >> 4) & 0x08u) | ((nb >> 2) & 0x10u) | (nb & 0x20u) | ((nb << 2) & 0x40u);
+}
+
 __global__ __launch_bounds__(64) void ksw_exact_match_kernel(const KswTask *__restrict__ tasks, int n,
                                                              const uint8_t *__restrict__ qseq,
                                                              const uint8_t *__restrict__ tseq,
@@ -115,10 +122,9 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 			const int force_state = fs[k];
 			uint32_t tmp = pf[k];
 			if (force_state < 0 && T.kind != GD_KIND_GENERIC) {
-				// wave kernels store (4-d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6 with n* = "no continuation"; rebuild the
-				// reference's byte d | cX<<3 | cY<<4 | cX2<<5 | cY2<<6 (SR/ksw2.h:127-130)
-				const uint32_t nb = ~tmp;
-				tmp = (4u - (tmp & 7u)) | ((nb >> 3) & 0x08u) | ((nb >> 1) & 0x10u) | ((nb << 1) & 0x20u) | ((nb << 3) & 0x40u);
+				// wave kernels store (4-d) | nY2<<4 | nX2<<5 | nY<<6 | nX<<7 with n* = "no continuation" (bit 3 undefined); rebuild
+				// the reference's byte d | cX<<3 | cY<<4 | cX2<<5 | cY2<<6 (SR/ksw2.h:127-130)
+				tmp = gd_bt_decode(tmp);
 			}
 			if (state == 0) state = tmp & 7;
 			else if (!(tmp >> (state + 2) & 1)) state = 0;
@@ -187,8 +193,7 @@ __device__ __forceinline__ void gd_bt_wave_walk(const KswTask &T, int tid, const
 			const int force_state = __builtin_amdgcn_readlane(fs, k);
 			uint32_t tmp = (uint32_t)__builtin_amdgcn_readlane((int)pf, k);
 			if (force_state < 0 && kind != GD_KIND_GENERIC) { // wave-kernel byte -> the reference's byte (see ksw_backtrack_kernel)
-				const uint32_t nb = ~tmp;
-				tmp = (4u - (tmp & 7u)) | ((nb >> 3) & 0x08u) | ((nb >> 1) & 0x10u) | ((nb << 1) & 0x20u) | ((nb << 3) & 0x40u);
+				tmp = gd_bt_decode(tmp);
 			}
 			if (state == 0) state = tmp & 7;
 			else if (!(tmp >> (state + 2) & 1)) state = 0;

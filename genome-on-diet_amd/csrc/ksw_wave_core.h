@@ -259,7 +259,7 @@ GDW_HD void gdw_reset_tr(WaveLane &L, const WaveK &K, const WaveRow &W)
 
 // One anti-diagonal for one ACTIVE lane.  pX/pV/pX2: register 7 of X/V/X2 of the previous lane (row r-1 values).
 // bt: the lane's 16 backtrace bytes of this row (4 dwords; byte 4g+h = cell 2g+(h&1)+8*(h>>1)).
-// backtrace byte = (4 - d) | nY2<<3 | nX2<<4 | nY<<5 | nX<<6, n* = "no continuation" (inverse of :263-272); bit 7 is undefined.
+// backtrace byte = (4 - d) | nY2<<4 | nX2<<5 | nY<<6 | nX<<7, n* = "no continuation" (inverse of :263-272); bit 3 is undefined.
 // DUAL = false: the single-affine recurrence of ksw_extz2 (K3).  With both gap models equal the second pair (a2, b2) can never
 // win the priority chain (equal value, lower tie code) and its continuation flags are never read by the backtrack, so the whole
 // X2 / Y2 half is dropped; the two flag bits are stored as "no continuation".
@@ -294,16 +294,16 @@ GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u
 		L.U[k] = nU, L.V[k] = nV;
 		if (k & 1) zk_hi = zk;
 		else {
-			// flags of register pairs k (cells k, k+8) and k+1 (cells k+1, k+9) together: the high byte of every 16-bit key
-			// carries its sign = "no continuation"; v_perm gathers them in backtrace byte order
-			const u32 hX = gdw_perm(L.X[k + 1], L.X[k], 0x07030501u), hY = gdw_perm(L.Y[k + 1], L.Y[k], 0x07030501u);
-			const u32 f1 = gdw_bfi_u(0x80808080u, hX, hY >> 1);
+			// flags of register pairs k (cells k, k+8) and k+1 (cells k+1, k+9) together: v_perm's sign selectors (8..11) turn the
+			// sign of every 16-bit key -- "no continuation" -- into a 0x00 / 0xff byte, already in backtrace byte order, so the four
+			// arrays merge with three v_bfi and no shift; the low nibble comes from the priority-chain key (bit 3 is undefined)
+			const u32 mX = gdw_perm(L.X[k + 1], L.X[k], 0x0b090a08u), mY = gdw_perm(L.Y[k + 1], L.Y[k], 0x0b090a08u);
 			u32 f;
 			if (DUAL) {
-				const u32 hX2 = gdw_perm(L.X2[k + 1], L.X2[k], 0x07030501u), hY2 = gdw_perm(L.Y2[k + 1], L.Y2[k], 0x07030501u);
-				f = gdw_bfi_u(0xc0c0c0c0u, f1, gdw_bfi_u(0x80808080u, hX2, hY2 >> 1) >> 2);
-			} else f = f1 | 0x30303030u;
-			bt[k >> 1] = gdw_bfi_u(0x78787878u, f >> 1, gdw_perm(zk_hi, zk, 0x06020400u));
+				const u32 mX2 = gdw_perm(L.X2[k + 1], L.X2[k], 0x0b090a08u), mY2 = gdw_perm(L.Y2[k + 1], L.Y2[k], 0x0b090a08u);
+				f = gdw_bfi_u(0x80808080u, mX, gdw_bfi_u(0x40404040u, mY, gdw_bfi_u(0x20202020u, mX2, mY2)));
+			} else f = gdw_bfi_u(0x80808080u, mX, mY) | 0x30303030u;
+			bt[k >> 1] = gdw_bfi_u(0xf0f0f0f0u, f, gdw_perm(zk_hi, zk, 0x06020400u));
 		}
 	}
 }

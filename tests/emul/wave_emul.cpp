@@ -101,8 +101,8 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 		for (int i = st; i <= en; ++i) {
 			const int c = i & 15, g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
 			const uint8_t b = bt[((size_t)r * LANES + ((i >> 4) % LANES)) * 16 + 4 * g + h];
-			const uint8_t ref = (uint8_t)((4 - (b & 7)) | (((b >> 6) & 1) ? 0 : 0x08) | (((b >> 5) & 1) ? 0 : 0x10) |
-			                              (((b >> 4) & 1) ? 0 : 0x20) | (((b >> 3) & 1) ? 0 : 0x40));
+			const uint8_t nb = (uint8_t)~b; // (4-d) | nY2<<4 | nX2<<5 | nY<<6 | nX<<7 -> d | cX<<3 | cY<<4 | cX2<<5 | cY2<<6
+			const uint8_t ref = (uint8_t)((4 - (b & 7)) | ((nb >> 4) & 0x08) | ((nb >> 2) & 0x10) | (nb & 0x20) | ((nb << 2) & 0x40));
 			p[(size_t)r * ncol * 16 + (i - st)] = ref;
 		}
 	}
