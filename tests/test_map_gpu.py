@@ -179,3 +179,62 @@ def test_device_built_index_equals_host_built(gpu_ctx, pkg, kind, monkeypatch):
     assert h[5] == d[5] and h[4] == d[4]
     for a, b in zip(h[:4], d[:4]):
         assert np.array_equal(a, b)
+
+
+@pytest.fixture(scope="module")
+def host_emulator(tmp_path_factory):
+    """the CPU driver of tests/test_map_host.py (the product's stage code compiled for the host + the oracle's DP), pinned to the
+    reference binary by the CPU suite; here it supplies expected SAM for read sets that have no committed golden file"""
+    import subprocess
+    from conftest import ROOT
+    d = tmp_path_factory.mktemp("emu")
+    exe = str(d / "map_host")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-w", "-I", os.path.join(ROOT, "genome-on-diet_amd", "csrc"),
+                           "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "emul", "map_host_main.cpp"),
+                           "-x", "c", os.path.join(ROOT, "oracle", "gdo_ksw2.c"), "-o", exe])
+    return exe, str(d)
+
+
+@pytest.mark.parametrize("kind,n,length", [("hifi", 160, 3000), ("ont", 20, 24000), ("sr", 4000, 150)])
+def test_fresh_reads_match_host_emulator(gpu_ctx, pkg, host_emulator, kind, n, length):
+    """a few thousand alignments per preset on reads drawn at test time (fixed seed): GPU path == host emulator, byte for byte"""
+    import gzip
+    import subprocess
+    import numpy as np
+    from fixture_io import cmd_of
+    exe, d = host_emulator
+    base, stem, preset = SETS[kind]
+    names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+    rng = np.random.default_rng({"hifi": 101, "ont": 102, "sr": 103}[kind])
+    sub, ind = {"hifi": (0.004, 0.002), "ont": (0.03, 0.02), "sr": (0.01, 0.001)}[kind]
+    comp = str.maketrans("ACGTN", "TGCAN")
+    reads = []
+    for i in range(n):
+        ln = length if kind == "sr" else int(rng.integers(length // 2, 2 * length))
+        c = int(rng.choice([j for j in range(len(seqs)) if len(seqs[j]) > ln + 10]))
+        st = int(rng.integers(0, len(seqs[c]) - ln))
+        s = np.frombuffer(seqs[c][st:st + ln].encode(), np.uint8).copy()
+        m = np.flatnonzero(rng.random(ln) < sub)
+        s[m] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=len(m))]
+        s = s[rng.random(len(s)) >= ind]
+        ip = np.flatnonzero(rng.random(len(s)) < ind)
+        s = np.insert(s, ip, np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=len(ip))])
+        q = s.tobytes().decode()
+        if rng.random() < 0.5:
+            q = q.translate(comp)[::-1]
+        reads.append(("f%d" % i, q, "I" * len(q)))
+    ref_fa, fq = os.path.join(d, kind + ".fa"), os.path.join(d, kind + ".fq")
+    with gzip.open(os.path.join(base, "ref.fa.gz"), "rb") as src, open(ref_fa, "wb") as dst:
+        dst.write(src.read())
+    with open(fq, "w") as f:
+        for nm, q, ql in reads:
+            f.write("@%s\n%s\n+\n%s\n" % (nm, q, ql))
+    want = subprocess.run([exe] + cmd_of(kind) + [ref_fa, fq], capture_output=True, text=True, check=True).stdout
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset=preset, **OVERRIDES.get(kind, {}))
+    try:
+        res = m.map([r[1] for r in reads])
+        assert m.sam_batch(res, reads) == want
+        mapped = sum(1 for i in range(n) if res.n_regs[i] > 0)
+        assert mapped > 0.5 * n
+    finally:
+        m.close()
