@@ -13,6 +13,22 @@ def read_range(n_reads, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def read_ranges_by_cost(lens, world, band=1000):
+    """contiguous ranges, one per rank, balanced by the DP cost of the reads rather than by their number: the
+    cost of a read is its number of DP cells, (2 * len - 1) * min(band + 1, len).  Returns world + 1 boundaries; order of reads
+    preserved (results are emitted in input order)."""
+    import numpy as np
+    lens = np.asarray(lens, np.int64)
+    cost = (2 * lens - 1).clip(min=0) * np.minimum(band + 1, lens)
+    cum = np.concatenate([[0], np.cumsum(cost)])
+    total = int(cum[-1])
+    bounds = [0]
+    for r in range(1, world):
+        bounds.append(max(bounds[-1], int(np.searchsorted(cum, total * r / world, side="left"))))
+    bounds.append(len(lens))
+    return bounds
+
+
 def rank_seed(base_seed, rank):
     """weak scaling: every rank draws its own reads (same distribution, different stream)"""
     return base_seed + rank

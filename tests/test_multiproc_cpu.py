@@ -66,3 +66,17 @@ def test_read_range_partitions_every_read_once(n, world):
         assert 0 <= lo <= hi <= n
         cover += list(range(lo, hi))
     assert cover == list(range(n))
+
+
+def test_cost_balanced_ranges():
+    """mixed read lengths: every read in exactly one range, ranges contiguous, DP cost per rank within one read of the ideal"""
+    import numpy as np
+    pkg = load_pkg()
+    rng = np.random.default_rng(3)
+    lens = np.concatenate([rng.integers(100, 300, size=5000), rng.integers(5000, 25000, size=300), rng.integers(100, 300, size=2000)])
+    for world in (1, 2, 8):
+        b = pkg.read_ranges_by_cost(lens, world)
+        assert b[0] == 0 and b[-1] == len(lens) and all(x <= y for x, y in zip(b, b[1:])) and len(b) == world + 1
+        cost = (2 * lens - 1) * np.minimum(1001, lens)
+        per = [int(cost[b[r]:b[r + 1]].sum()) for r in range(world)]
+        assert max(per) - min(per) <= 2 * int(cost.max())
