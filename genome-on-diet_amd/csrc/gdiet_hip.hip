@@ -39,6 +39,7 @@ struct gdiet_ctx {
 	hipStream_t stream_dp = nullptr;   // stream of the DP stage in an async lane (GDIET_DP_PRIORITY=1 raises its priority)
 	hipEvent_t ev2[3] = {nullptr, nullptr, nullptr}; // go, DP of the tail done, tail done
 	int dp_split = 1, wave_slots = 5120, last_split = 0;
+	int vote_wave = 1;                 // GDIET_VOTE_WAVE=0: the sequential vote kernel for long reads too
 	int index_on_device = 1;           // GDIET_INDEX_BUILD=host: gdiet_hip_index_build sketches and sorts on host threads instead
 	int fuse_bt = 1;                   // GDIET_FUSE_BT=0: the 64-lane kernel leaves the backtrack to the separate kernel
 	bool single_affine = false;        // set for the duration of a gdiet_hip_ksw_extz2_batch call: single-affine kernel variants
@@ -150,6 +151,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (sl && atoi(sl) > 0) ctx->slices_per_lane = atoi(sl);
 		const char *bw = getenv("GDIET_BT_WAVE");
 		if (bw) ctx->bt_wave = atoi(bw) != 0;
+		const char *vw = getenv("GDIET_VOTE_WAVE");
+		if (vw) ctx->vote_wave = atoi(vw) != 0;
 		const char *ib = getenv("GDIET_INDEX_BUILD");
 		if (ib) ctx->index_on_device = strcmp(ib, "host") != 0;
 		const char *fb = getenv("GDIET_FUSE_BT");

@@ -97,6 +97,111 @@ __global__ __launch_bounds__(64) void map_vote_kernel(int n_reads, const int64_t
 	else o.n_cand = gd_lr_candidates(a_for, nf, sr, nr, (uint32_t)len, (int32_t)so.tel, O.vote, o.cand);
 }
 
+// ---- wave-parallel form of map_vote_kernel: one 64-lane wavefront per read ----------------------------------------------------
+// The occurrences of 64 seeds are expanded side by side (ballot + prefix count give every hit its slot on its strand), each
+// strand's hits are sorted by target with a wavefront bitonic sort in LDS, and lane 0 runs the vote scans on the LDS copy.
+// Reads with more than MAP_VOTE_CAP hits on a strand take the sequential path of map_vote_kernel (same code, one lane).
+#define MAP_VOTE_CAP 2048
+
+__device__ __forceinline__ void map_bitonic_locs(GdLoc *a, unsigned P2, unsigned lane)
+{
+	for (unsigned kk = 2; kk <= P2; kk <<= 1)
+		for (unsigned jj = kk >> 1; jj > 0; jj >>= 1) {
+			for (unsigned i = lane; i < P2; i += 64) {
+				const unsigned ixj = i ^ jj;
+				if (ixj > i) {
+					const GdLoc x = a[i], y = a[ixj];
+					const bool up = (i & kk) == 0;
+					if ((x.target > y.target) == up) a[i] = y, a[ixj] = x;
+				}
+			}
+			__syncthreads();
+		}
+}
+
+__global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const int64_t *__restrict__ roff, GdIdxView I, MapDevOpt O,
+                                                           const MapReadScratch *__restrict__ sc, const GdSeed *__restrict__ seed_arena,
+                                                           const MapSeedOut *__restrict__ seeds, const int64_t *__restrict__ hit_off,
+                                                           GdLoc *__restrict__ hits, MapVoteOut *__restrict__ out)
+{
+	__shared__ GdLoc s_for[MAP_VOTE_CAP], s_rev[MAP_VOTE_CAP];
+	const int rid = blockIdx.x;
+	if (rid >= n_reads) return;
+	const unsigned lane = threadIdx.x;
+	MapVoteOut &o = out[rid];
+	const MapSeedOut so = seeds[rid];
+	if (so.n_seeds <= 0) { if (lane == 0) o.n_cand = 0, o.pad = 0; return; }
+	const int len = (int)(roff[rid + 1] - roff[rid]);
+	const int64_t na = so.n_a;
+	GdLoc *a_for = hits + 3 * hit_off[rid], *a_rev = a_for + na, *tmp = a_rev + na;
+	const GdSeed *m = seed_arena + sc[rid].seed_off;
+	// S6: expansion, 64 seeds at a time (gd_seed_hits; the order inside a strand is irrelevant: it is sorted next)
+	unsigned nf = 0, nr = 0;
+	for (int base = 0; base < so.n_seeds; base += 64) {
+		const int si = base + (int)lane;
+		GdSeed q;
+		q.n = 0, q.q_pos = 0, q.start = 0, q.flt = 0;
+		if (si < so.n_seeds) q = m[si];
+		unsigned mx = q.n;
+		for (int d = 32; d > 0; d >>= 1) { const unsigned v = __shfl_xor(mx, d); mx = v > mx ? v : mx; }
+		for (unsigned k = 0; k < mx; ++k) {
+			bool is_for = false, is_rev = false;
+			GdLoc L;
+			L.target = 0, L.query = 0, L.pad = 0;
+			if (k < q.n) {
+				const uint64_t r = I.pos[(uint64_t)q.start + k];
+				bool skip = false;
+				if (O.flag & (GDM_F_FOR_ONLY | GDM_F_REV_ONLY)) { // skip_seed, LR/map.c:724-730
+					if ((r & 1) == (q.q_pos & 1)) skip = (O.flag & GDM_F_REV_ONLY) != 0;
+					else skip = (O.flag & GDM_F_FOR_ONLY) != 0;
+				}
+				if (!skip) {
+					const uint32_t qpos = q.q_pos >> 1;
+					const unsigned str = (unsigned)((r & 1) ^ (q.q_pos & 1));
+					uint32_t loc = (uint32_t)r >> 1;
+					loc = str ? loc + qpos : loc + so.tel - qpos;
+					L.target = (r >> 32) << 32 | loc, L.query = qpos;
+					is_rev = str != 0, is_for = !is_rev;
+				}
+			}
+			const uint64_t bf = __ballot(is_for), br = __ballot(is_rev);
+			const uint64_t below = (1ull << lane) - 1;
+			if (is_for) a_for[nf + __popcll(bf & below)] = L;
+			if (is_rev) a_rev[nr + __popcll(br & below)] = L;
+			nf += __popcll(bf), nr += __popcll(br);
+		}
+	}
+	__syncthreads();
+	if (nf > MAP_VOTE_CAP || nr > MAP_VOTE_CAP) { // too many hits for the LDS buffers: the sequential path on the global arrays
+		if (lane == 0) {
+			o.pad = 0;
+			GdLoc *sf = gd_sort_locs(a_for, tmp, nf);
+			if (sf != a_for) for (unsigned i = 0; i < nf; ++i) a_for[i] = sf[i];
+			GdLoc *sr = gd_sort_locs(a_rev, tmp, nr);
+			if (O.is_sr) o.n_cand = gd_sr_candidates(a_for, nf, sr, nr, (uint32_t)len, so.tel, so.n_mv, O.sr, o.cand);
+			else o.n_cand = gd_lr_candidates(a_for, nf, sr, nr, (uint32_t)len, (int32_t)so.tel, O.vote, o.cand);
+		}
+		return;
+	}
+	// S7: both strands into LDS, padded with +inf to a power of two, bitonic sort by target
+	unsigned Pf = 64, Pr = 64;
+	while (Pf < nf) Pf <<= 1;
+	while (Pr < nr) Pr <<= 1;
+	GdLoc inf;
+	inf.target = UINT64_MAX, inf.query = 0, inf.pad = 0;
+	for (unsigned i = lane; i < Pf; i += 64) s_for[i] = i < nf ? a_for[i] : inf;
+	for (unsigned i = lane; i < Pr; i += 64) s_rev[i] = i < nr ? a_rev[i] : inf;
+	__syncthreads();
+	map_bitonic_locs(s_for, Pf, lane);
+	map_bitonic_locs(s_rev, Pr, lane);
+	// V1 / V2 / V3 / G1a: the sequential scans, on the LDS copy
+	if (lane == 0) {
+		o.pad = 0;
+		if (O.is_sr) o.n_cand = gd_sr_candidates(s_for, nf, s_rev, nr, (uint32_t)len, so.tel, so.n_mv, O.sr, o.cand);
+		else o.n_cand = gd_lr_candidates(s_for, nf, s_rev, nr, (uint32_t)len, (int32_t)so.tel, O.vote, o.cand);
+	}
+}
+
 // one DP box: where its query / target windows come from and where they go in the packed ksw batch buffers
 struct MapBox {
 	int64_t read_off;   // offset of the read in the nt4 read buffer
@@ -138,6 +243,8 @@ __global__ __launch_bounds__(64) void map_pack_cigar_kernel(int nb, const uint32
 // The winnowing automaton is sequential, but exact slices of it can be produced independently (gd_sketch_slice), so the 64
 // lanes sketch 64 slices of the read, compact their minimizers in read order with a wavefront prefix sum, probe the index
 // in parallel, and leave only the short sequential parts (query-occurrence filter, high-occurrence seed selection) to lane 0.
+#define MAP_SORT_CAP 2048 // hashes of one read the seed kernel sorts in LDS (16 KB)
+
 struct GdEmitLane { // per-lane emission list in scratch
 	GdMini *out;
 	unsigned n, cap;
@@ -233,12 +340,40 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 		if (n_mv == ~0u) { o.n_seeds = -1; if (lane == 0) out[rid] = o; return; }
 		if (O.max_nb_seeds != UINT32_MAX && O.max_nb_seeds > 0 && n_mv == O.max_nb_seeds) o.tel = (uint32_t)(mv[n_mv - 1].y >> 1); // :2010-2012
 	}
-	// S4: mm_seed_mz_flt (sequential; needs the sorted multiset of hashes)
-	if (O.q_occ_frac > 0.0f && (int64_t)n_mv > (int64_t)O.mid_occ) {
-		unsigned nn = 0;
-		if (lane == 0) nn = gd_mz_flt(mv, n_mv, O.mid_occ, O.q_occ_frac, u64_arena + S.u64_off);
-		__syncthreads();
-		n_mv = __shfl(nn, 0);
+	// S4: mm_seed_mz_flt.  It only ever drops something when one hash occurs more than mid_occ times in the read, which a
+	// wavefront bitonic sort of the hashes in LDS decides in a few microseconds (a run longer than mid_occ <=> s[i] == s[i + mid_occ]
+	// for some i); only then -- practically never -- does lane 0 run the sequential filter.  Lists too long for the LDS buffer
+	// (ONT reads) take the sequential path directly.
+	if (O.q_occ_frac > 0.0f && (int64_t)n_mv > (int64_t)O.mid_occ && O.mid_occ > 0) {
+		__shared__ uint64_t srt[MAP_SORT_CAP];
+		bool need = true;
+		if (n_mv <= MAP_SORT_CAP) {
+			unsigned P2 = 64;
+			while (P2 < n_mv) P2 <<= 1;
+			for (unsigned i = lane; i < P2; i += 64) srt[i] = i < n_mv ? mv[i].x : UINT64_MAX;
+			__syncthreads();
+			for (unsigned kk = 2; kk <= P2; kk <<= 1)
+				for (unsigned jj = kk >> 1; jj > 0; jj >>= 1) {
+					for (unsigned i = lane; i < P2; i += 64) {
+						const unsigned ixj = i ^ jj;
+						if (ixj > i) {
+							const uint64_t a = srt[i], b = srt[ixj];
+							const bool up = (i & kk) == 0;
+							if ((a > b) == up) srt[i] = b, srt[ixj] = a;
+						}
+					}
+					__syncthreads();
+				}
+			bool hit = false;
+			for (unsigned i = lane; i + (unsigned)O.mid_occ < n_mv; i += 64) hit |= srt[i] == srt[i + (unsigned)O.mid_occ];
+			need = __any(hit);
+		}
+		if (need) {
+			unsigned nn = 0;
+			if (lane == 0) nn = gd_mz_flt(mv, n_mv, O.mid_occ, O.q_occ_frac, u64_arena + S.u64_off);
+			__syncthreads();
+			n_mv = __shfl(nn, 0);
+		}
 	}
 	// S5: probes in parallel, then the sequential selection
 	for (unsigned j = lane; j < n_mv; j += 64) gd_collect_probe(I, mv[j], seeds[j]);

@@ -411,10 +411,15 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	if ((rc = gd_grow(ctx, ctx->m_hits, sizeof(GdLoc) * 3 * (size_t)(hoff[n] + 1)))) return rc;
 	GD_HIP(hipMemcpyAsync(ctx->m_hitoff.p, hoff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s));
 	// ---- S6, S7, V1, V3, G1a -----------------------------------------------------------------------------------------
-	const int spread = ctx->spread && (B.roff[n] - B.roff[0]) / n >= 1024; // long reads: one read per wavefront; short reads: per thread
-	hipLaunchKernelGGL(map_vote_kernel, dim3(spread ? n : (n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
-	                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
-	                   (MapVoteOut *)ctx->m_voteout.p, spread);
+	// long reads: one read per wavefront (parallel expansion + LDS sort); short reads (a handful of hits each): one read per thread
+	const int spread = ctx->spread && (B.roff[n] - B.roff[0]) / n >= 1024;
+	if (spread == 1 && ctx->vote_wave)
+		hipLaunchKernelGGL(map_vote_wave_kernel, dim3(n), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p, (const GdSeed *)ctx->m_seed.p,
+		                   (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p, (MapVoteOut *)ctx->m_voteout.p);
+	else
+		hipLaunchKernelGGL(map_vote_kernel, dim3(spread ? n : (n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+		                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
+		                   (MapVoteOut *)ctx->m_voteout.p, spread);
 	// only the head of every record can be in use: n_cand + at most AF_max_loc (ShortReads) / vt_nb_loc + 2 (LongReads) candidates;
 	// the host copy is packed to that size (a full-size array would be 680 B per read: 178 MB to allocate and clear per 262 k short reads)
 	const size_t vo_head = offsetof(MapVoteOut, cand) + sizeof(GdVt) * std::min<size_t>(is_sr ? (size_t)O.af_max_loc : (size_t)O.vt_nb_loc + 2, GDM_MAX_VT);
@@ -593,7 +598,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		gdiet_ctx *c = nullptr;
 		int rc = gdiet_hip_init(&c, ctx->device);
 		if (rc) { ctx->err = "cannot create a pipeline lane"; return rc; }
-		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt;
+		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave;
 		ctx->children.push_back(c);
 	}
 	const int n_slices = std::min(n, lanes * ctx->slices_per_lane);
@@ -668,7 +673,7 @@ extern "C" int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *ix, const
 		ctx->async_lane[l] = c;
 	}
 	gdiet_ctx *c = ctx->async_lane[l];
-	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt;
+	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave;
 	c->lane_threads = c->host_threads = std::max(1, ctx->host_threads / ctx->async_depth);
 	ctx->async_busy[l] = true, ctx->async_next++;
 	t->lane = l;
