@@ -99,9 +99,35 @@ __global__ __launch_bounds__(64) void map_vote_kernel(int n_reads, const int64_t
 
 // ---- wave-parallel form of map_vote_kernel: one 64-lane wavefront per read ----------------------------------------------------
 // The occurrences of 64 seeds are expanded side by side (ballot + prefix count give every hit its slot on its strand), each
-// strand's hits are sorted by target with a wavefront bitonic sort in LDS, and lane 0 runs the vote scans on the LDS copy.
+// strand's hits are sorted by target with a wavefront bitonic sort in LDS, and the whole wavefront runs the (wave-uniform) vote
+// scans in lockstep on a 64-hits-per-round-trip view of the sorted arrays.
 // Reads with more than MAP_VOTE_CAP hits on a strand take the sequential path of map_vote_kernel (same code, one lane).
-#define MAP_VOTE_CAP 2048
+#define MAP_VOTE_CAP 4096
+
+// Front-to-back view of a sorted hit array for the vote scans, executed by ALL lanes of the wavefront in lockstep: the lanes
+// load 64 consecutive hits at once and hand them out through v_readlane, so the (wave-uniform, hence scalar) scan pays one LDS
+// round trip per 64 hits instead of one per hit.
+struct MapWaveLocs {
+	const GdLoc *base;
+	unsigned n;
+	mutable unsigned chunk;
+	mutable uint64_t t;
+	mutable uint32_t q;
+	__device__ GdLoc operator[](unsigned i) const
+	{
+		const unsigned c = i & ~63u;
+		if (c != chunk) {
+			chunk = c;
+			const unsigned j = c + (threadIdx.x & 63);
+			t = j < n ? base[j].target : ~0ull, q = j < n ? base[j].query : 0u;
+		}
+		const int l = (int)(i & 63);
+		GdLoc r;
+		r.target = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), l) << 32;
+		r.query = (uint32_t)__builtin_amdgcn_readlane((int)q, l), r.pad = 0;
+		return r;
+	}
+};
 
 __device__ __forceinline__ void map_bitonic_locs(GdLoc *a, unsigned P2, unsigned lane)
 {
@@ -124,7 +150,7 @@ __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const in
                                                            const MapSeedOut *__restrict__ seeds, const int64_t *__restrict__ hit_off,
                                                            GdLoc *__restrict__ hits, MapVoteOut *__restrict__ out)
 {
-	__shared__ GdLoc s_for[MAP_VOTE_CAP], s_rev[MAP_VOTE_CAP];
+	__shared__ GdLoc s_buf[MAP_VOTE_CAP]; // one strand at a time: 64 KB
 	const int rid = blockIdx.x;
 	if (rid >= n_reads) return;
 	const unsigned lane = threadIdx.x;
@@ -183,23 +209,33 @@ __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const in
 		}
 		return;
 	}
-	// S7: both strands into LDS, padded with +inf to a power of two, bitonic sort by target
-	unsigned Pf = 64, Pr = 64;
-	while (Pf < nf) Pf <<= 1;
-	while (Pr < nr) Pr <<= 1;
+	// S7: one strand at a time through LDS: padded with +inf to a power of two, bitonic sort by target, back to its global array
 	GdLoc inf;
 	inf.target = UINT64_MAX, inf.query = 0, inf.pad = 0;
-	for (unsigned i = lane; i < Pf; i += 64) s_for[i] = i < nf ? a_for[i] : inf;
-	for (unsigned i = lane; i < Pr; i += 64) s_rev[i] = i < nr ? a_rev[i] : inf;
-	__syncthreads();
-	map_bitonic_locs(s_for, Pf, lane);
-	map_bitonic_locs(s_rev, Pr, lane);
-	// V1 / V2 / V3 / G1a: the sequential scans, on the LDS copy
-	if (lane == 0) {
-		o.pad = 0;
-		if (O.is_sr) o.n_cand = gd_sr_candidates(s_for, nf, s_rev, nr, (uint32_t)len, so.tel, so.n_mv, O.sr, o.cand);
-		else o.n_cand = gd_lr_candidates(s_for, nf, s_rev, nr, (uint32_t)len, (int32_t)so.tel, O.vote, o.cand);
+	for (int strand = 0; strand < 2; ++strand) {
+		GdLoc *g = strand ? a_rev : a_for;
+		const unsigned cnt = strand ? nr : nf;
+		if (cnt < 2) continue;
+		unsigned P2 = 64;
+		while (P2 < cnt) P2 <<= 1;
+		for (unsigned i = lane; i < P2; i += 64) s_buf[i] = i < cnt ? g[i] : inf;
+		__syncthreads();
+		map_bitonic_locs(s_buf, P2, lane);
+		for (unsigned i = lane; i < cnt; i += 64) g[i] = s_buf[i];
+		__syncthreads();
 	}
+	// V1 / V2 / V3 / G1a: the scans are sequential in the hits but wave-uniform, so every lane runs them in lockstep on a
+	// prefetching view of the sorted arrays (MapWaveLocs); the candidate list lives in LDS, lane by lane identical
+	__shared__ GdVt s_cand[GDM_MAX_VT];
+	__shared__ unsigned s_ncand;
+	const MapWaveLocs vf = {a_for, nf, ~0u, 0, 0}, vr = {a_rev, nr, ~0u, 0, 0}; // the sorted global arrays, 64 hits per round trip
+	unsigned nc;
+	if (O.is_sr) nc = gd_sr_candidates(vf, nf, vr, nr, (uint32_t)len, so.tel, so.n_mv, O.sr, s_cand);
+	else nc = gd_lr_candidates(vf, nf, vr, nr, (uint32_t)len, (int32_t)so.tel, O.vote, s_cand);
+	if (lane == 0) s_ncand = nc;
+	__syncthreads();
+	if (lane == 0) o.n_cand = s_ncand, o.pad = 0;
+	for (unsigned i = lane; i < s_ncand; i += 64) o.cand[i] = s_cand[i];
 }
 
 // one DP box: where its query / target windows come from and where they go in the packed ksw batch buffers

@@ -471,7 +471,10 @@ GDM_HD void gd_vt_insert(GdVt *seqs, unsigned &out_len, unsigned max_n, unsigned
 	}
 }
 
-GDM_HD void gd_vote(const GdLoc *loc, unsigned len, int str, GdVt *seqs, unsigned *nb_seqs, uint32_t vt_distance, int32_t tel,
+// LocSrc: anything with operator[](unsigned) -> GdLoc, read front to back (a pointer on the host; on the device a wavefront-wide
+// prefetching view, see map_kernels.hip.h)
+template <class LocSrc>
+GDM_HD void gd_vote(LocSrc loc, unsigned len, int str, GdVt *seqs, unsigned *nb_seqs, uint32_t vt_distance, int32_t tel,
                     unsigned max_n, uint32_t cov_thr)
 {
 	if (len == 0) return;
@@ -504,7 +507,8 @@ GDM_HD void gd_vote(const GdLoc *loc, unsigned len, int str, GdVt *seqs, unsigne
 }
 
 // ---- V3: vote_2 (LR/map.c:1182-1271): best single run restricted to query interval (min,max) ------------------------------
-GDM_HD void gd_vote2(const GdLoc *loc, unsigned len, int str, GdVt *vt, uint32_t vt_distance, int32_t tel, uint32_t qmin, uint32_t qmax)
+template <class LocSrc>
+GDM_HD void gd_vote2(LocSrc loc, unsigned len, int str, GdVt *vt, uint32_t vt_distance, int32_t tel, uint32_t qmin, uint32_t qmax)
 {
 	if (len == 0) return;
 	GdVt best = *vt;
@@ -547,7 +551,8 @@ struct GdLrVoteOpt {
 #define GDM_MAX_VT 24 // vt_nb_loc + 2 (LongReads) / AF_max_loc (ShortReads, default 20) must fit
 
 // seqs[] must hold vt_nb_loc+2 entries.  Returns the number of candidates (0: unmapped).
-GDM_HD unsigned gd_lr_candidates(const GdLoc *a_for, unsigned n_for, const GdLoc *a_rev, unsigned n_rev, uint32_t qlen_sum,
+template <class LocSrc>
+GDM_HD unsigned gd_lr_candidates(LocSrc a_for, unsigned n_for, LocSrc a_rev, unsigned n_rev, uint32_t qlen_sum,
                                  int32_t tel, const GdLrVoteOpt &O, GdVt *seqs)
 {
 	const uint32_t cov_thr = (uint32_t)((float)qlen_sum * O.vt_cov); // :1342
@@ -641,7 +646,8 @@ GDM_HD void gd_sr_vt_close(GdVt *pot, unsigned &out_len, GdVt &recovery, unsigne
 		gd_sr_vt_set(recovery, target_loc, fq, lq, str, counter, tel);
 }
 
-GDM_HD void gd_vote_sr(const GdLoc *loc, unsigned len, int str, GdVt *pot, unsigned *nb, uint32_t vt_distance, uint32_t tel, GdVt &recovery,
+template <class LocSrc>
+GDM_HD void gd_vote_sr(LocSrc loc, unsigned len, int str, GdVt *pot, unsigned *nb, uint32_t vt_distance, uint32_t tel, GdVt &recovery,
                        unsigned vt_threshold, unsigned max_n, unsigned vt_rec_threshold)
 {
 	if (len == 0) return;
@@ -664,7 +670,8 @@ GDM_HD void gd_vote_sr(const GdLoc *loc, unsigned len, int str, GdVt *pot, unsig
 }
 
 // the candidate list of one short read, SR/map.c:664-699; n_mv = mv.n after mm_seed_mz_flt.  pot[] holds af_max_loc entries.
-GDM_HD unsigned gd_sr_candidates(const GdLoc *a_for, unsigned n_for, const GdLoc *a_rev, unsigned n_rev, uint32_t qlen_sum, uint32_t tel,
+template <class LocSrc>
+GDM_HD unsigned gd_sr_candidates(LocSrc a_for, unsigned n_for, LocSrc a_rev, unsigned n_rev, uint32_t qlen_sum, uint32_t tel,
                                  uint32_t n_mv, const GdSrVoteOpt &O, GdVt *pot)
 {
 	const bool frag = O.frag_mode && tel < qlen_sum;
