@@ -295,13 +295,13 @@ struct GdEmitLane { // per-lane emission list in scratch
 // parallel sketch of `dl` sparsified bases; the first min(total, cap) minimizers in read order go to dst[0..).
 // Returns (uniform) the count, or ~0u when a scratch list or dst overflowed.
 __device__ unsigned map_par_sketch(const uint8_t *str, unsigned dl, int w, int k, unsigned shift, const GdPattern &P, GdMini *tmp,
-                                   unsigned R, GdMini *dst, unsigned dst_cap, uint32_t cap)
+                                   unsigned R, GdMini *dst, unsigned dst_cap, uint32_t cap, GdMini *win /* LDS: w x 64 entries, lane-interleaved */)
 {
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned chunk = (dl + 63) / 64;
 	const unsigned i0 = lane * chunk, i1 = i0 + chunk < dl ? i0 + chunk : dl;
 	GdEmitLane e = {tmp + (size_t)lane * R, 0, R};
-	if (chunk && i0 < dl) gd_sketch_slice(str, dl, i0, i1, w, k, 0, shift, P, true, e);
+	if (chunk && i0 < dl) gd_sketch_slice(str, dl, i0, i1, w, k, 0, shift, P, true, e, win + lane, 64);
 	unsigned incl = e.n;
 	for (int d = 1; d < 64; d <<= 1) {
 		const unsigned v = __shfl_up(incl, d);
@@ -336,6 +336,9 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	GdMini *tmp = (GdMini *)(u64_arena + S.u64_off); // 2*mv_cap uint64 = mv_cap GdMini
 	GdSeed *seeds = seed_arena + S.seed_off;
 	const unsigned R = S.mv_cap / 64;
+	// dynamic LDS: the winnowing windows of the 64 lanes (w x 64 entries, lane-interleaved), reused by the hash sort of S4
+	extern __shared__ __attribute__((aligned(16))) uint8_t seed_lds[];
+	GdMini *win = reinterpret_cast<GdMini *>(seed_lds);
 	// S1: mm_sketch2 -- every phase, phase 0 on the cropped read, later phases capped at phase 0's count (LR/sketch.c:2174-2223)
 	unsigned len_crop, total = 0;
 	uint32_t cap;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	bool bad = false;
 	for (int shift = 0; shift < O.pat.W; ++shift) {
 		const unsigned dl = gd_diet_len(O.pat, len_crop, (unsigned)shift);
-		const unsigned n = map_par_sketch(str, dl, O.w, O.k, (unsigned)shift, O.pat, tmp, R, mv + total, S.mv_cap - total, cap == UINT32_MAX ? 0u : cap);
+		const unsigned n = map_par_sketch(str, dl, O.w, O.k, (unsigned)shift, O.pat, tmp, R, mv + total, S.mv_cap - total, cap == UINT32_MAX ? 0u : cap, win);
 		__syncthreads();
 		if (n == ~0u) { bad = true; break; }
 		shift_n[shift] = n, total += n;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	unsigned n_mv;
 	{
 		const unsigned dl = gd_diet_len(O.pat, (unsigned)len, (unsigned)o.shift);
-		n_mv = map_par_sketch(str, dl, O.w, O.k, (unsigned)o.shift, O.pat, tmp, R, mv, S.mv_cap, O.max_nb_seeds == UINT32_MAX ? 0u : O.max_nb_seeds);
+		n_mv = map_par_sketch(str, dl, O.w, O.k, (unsigned)o.shift, O.pat, tmp, R, mv, S.mv_cap, O.max_nb_seeds == UINT32_MAX ? 0u : O.max_nb_seeds, win);
 		__syncthreads();
 		if (n_mv == ~0u) { o.n_seeds = -1; if (lane == 0) out[rid] = o; return; }
 		if (O.max_nb_seeds != UINT32_MAX && O.max_nb_seeds > 0 && n_mv == O.max_nb_seeds) o.tel = (uint32_t)(mv[n_mv - 1].y >> 1); // :2010-2012
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	// for some i); only then -- practically never -- does lane 0 run the sequential filter.  Lists too long for the LDS buffer
 	// (ONT reads) take the sequential path directly.
 	if (O.q_occ_frac > 0.0f && (int64_t)n_mv > (int64_t)O.mid_occ && O.mid_occ > 0) {
-		__shared__ uint64_t srt[MAP_SORT_CAP];
+		uint64_t *srt = reinterpret_cast<uint64_t *>(seed_lds); // the window storage is idle now
 		bool need = true;
 		if (n_mv <= MAP_SORT_CAP) {
 			unsigned P2 = 64;

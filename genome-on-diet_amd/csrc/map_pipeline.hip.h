@@ -393,7 +393,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 		else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
-			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), std::max<size_t>((size_t)O.w * 64 * sizeof(GdMini), MAP_SORT_CAP * sizeof(uint64_t)), s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 		GD_HIP(hipMemcpyAsync(so.data(), ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
 		GD_HIP(hipStreamSynchronize(s));

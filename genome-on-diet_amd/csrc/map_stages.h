@@ -69,15 +69,20 @@ GDM_HD unsigned gd_diet_len(const GdPattern &P, unsigned len, unsigned shift)
 // matters below w+k), so a slice [i_emit, i_end) can be produced exactly by starting w+k steps earlier with the true l
 // and suppressing every emission before i_emit.  i_begin/l_init describe that warm-up start; do_final = the slice is the
 // last one and performs the end-of-sequence flush.
+// win / wstride: storage of the w-entry window (entry j at win[j * wstride]); nullptr = a local array.  The wave-parallel device
+// kernels pass lane-interleaved LDS (a dynamically indexed local array lives in scratch memory there, an order of magnitude slower).
 template <class Emit>
 GDM_HD void gd_sketch_range(const uint8_t *str, unsigned i_begin, unsigned i_emit, unsigned i_end, int l_init, bool do_final, int w, int k,
-                            uint32_t rid, unsigned shift, const GdPattern &P, bool final_ge, Emit &emit)
+                            uint32_t rid, unsigned shift, const GdPattern &P, bool final_ge, Emit &emit, GdMini *win = nullptr, int wstride = 1)
 {
 	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
 	uint64_t kmer[2] = {0, 0};
-	GdMini buf[GDM_MAX_W], mn = {UINT64_MAX, UINT64_MAX};
+	GdMini own[GDM_MAX_W], mn = {UINT64_MAX, UINT64_MAX};
+	GdMini *const wb = win ? win : own;
+	const int ws = win ? wstride : 1;
+#define buf(j_) wb[(j_) * ws]
 	int l = l_init, buf_pos = 0, min_pos = 0;
-	for (int j = 0; j < w; ++j) buf[j].x = buf[j].y = UINT64_MAX;
+	for (int j = 0; j < w; ++j) buf(j).x = buf(j).y = UINT64_MAX;
 #define GDM_EMIT(m_) do { if (i >= i_emit) { if (emit(m_)) return; } } while (0)
 	for (unsigned i = i_begin; i < i_end; ++i) {
 		const unsigned real = (i / P.ones) * P.W + P.ones_loc[i % P.ones] + shift; // get_real_location, :20-23
@@ -99,7 +104,7 @@ GDM_HD void gd_sketch_range(const uint8_t *str, unsigned i_begin, unsigned i_emi
 			if (l >= w + k - 1 && mn.x != UINT64_MAX) GDM_EMIT(mn);
 			l = 0;
 		}
-		buf[buf_pos] = info;
+		buf(buf_pos) = info;
 		if (info.x <= mn.x) { // a new minimum (ties: the rightmost wins); write the old one
 			if (l >= w + k && mn.x != UINT64_MAX) GDM_EMIT(mn);
 			mn = info, min_pos = buf_pos;
@@ -107,25 +112,26 @@ GDM_HD void gd_sketch_range(const uint8_t *str, unsigned i_begin, unsigned i_emi
 			if (l >= w + k - 1 && mn.x != UINT64_MAX) GDM_EMIT(mn);
 			mn.x = UINT64_MAX;
 			for (int j = buf_pos + 1; j < w; ++j)
-				if (mn.x >= buf[j].x) mn = buf[j], min_pos = j;
+				if (mn.x >= buf(j).x) mn = buf(j), min_pos = j;
 			for (int j = 0; j <= buf_pos; ++j)
-				if (mn.x >= buf[j].x) mn = buf[j], min_pos = j;
+				if (mn.x >= buf(j).x) mn = buf(j), min_pos = j;
 			if (l >= w + k - 1 && mn.x != UINT64_MAX) { // identical k-mers in the window
 				for (int j = buf_pos + 1; j < w; ++j)
-					if (mn.x == buf[j].x && mn.y != buf[j].y) GDM_EMIT(buf[j]);
+					if (mn.x == buf(j).x && mn.y != buf(j).y) GDM_EMIT(buf(j));
 				for (int j = 0; j <= buf_pos; ++j)
-					if (mn.x == buf[j].x && mn.y != buf[j].y) GDM_EMIT(buf[j]);
+					if (mn.x == buf(j).x && mn.y != buf(j).y) GDM_EMIT(buf(j));
 			}
 		}
 		if (l == w + k - 1 && mn.x != UINT64_MAX) { // first full window: identical k-mers were not written yet
 			for (int j = buf_pos + 1; j < w; ++j)
-				if (mn.x == buf[j].x && buf[j].y != mn.y) GDM_EMIT(buf[j]);
+				if (mn.x == buf(j).x && buf(j).y != mn.y) GDM_EMIT(buf(j));
 			for (int j = 0; j < buf_pos; ++j)
-				if (mn.x == buf[j].x && buf[j].y != mn.y) GDM_EMIT(buf[j]);
+				if (mn.x == buf(j).x && buf(j).y != mn.y) GDM_EMIT(buf(j));
 		}
 		if (++buf_pos == w) buf_pos = 0;
 	}
 #undef GDM_EMIT
+#undef buf
 	if (do_final && (final_ge ? l >= w + k - 1 : l > w + k - 1) && mn.x != UINT64_MAX) emit(mn);
 }
 
@@ -140,7 +146,7 @@ GDM_HD void gd_sketch_core(const uint8_t *str, unsigned diet_len, int w, int k, 
 // bases in front of it, then runs the automaton (see gd_sketch_range)
 template <class Emit>
 GDM_HD void gd_sketch_slice(const uint8_t *str, unsigned diet_len, unsigned i_emit, unsigned i_end, int w, int k, uint32_t rid,
-                            unsigned shift, const GdPattern &P, bool final_ge, Emit &emit)
+                            unsigned shift, const GdPattern &P, bool final_ge, Emit &emit, GdMini *win = nullptr, int wstride = 1)
 {
 	const unsigned wu = (unsigned)(w + k);
 	const unsigned i_begin = i_emit > wu ? i_emit - wu : 0;
@@ -153,7 +159,7 @@ GDM_HD void gd_sketch_slice(const uint8_t *str, unsigned diet_len, unsigned i_em
 			++l0;
 		}
 	}
-	gd_sketch_range(str, i_begin, i_emit, i_end, l0, i_end >= diet_len, w, k, rid, shift, P, final_ge, emit);
+	gd_sketch_range(str, i_begin, i_emit, i_end, l0, i_end >= diet_len, w, k, rid, shift, P, final_ge, emit, win, wstride);
 }
 
 // ---- flat index view (device mirror of mm_idx_t's buckets; built by map_index.h) -------------------------------
