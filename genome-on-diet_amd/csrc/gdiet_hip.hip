@@ -452,7 +452,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		                 d_status, d_score, K, stream, single);
 	if (!ids[GD_KIND_WAVE128].empty())
 		gd_launch_wave128(d_tasks, d_ids + id_off[GD_KIND_WAVE128], (int)ids[GD_KIND_WAVE128].size(), d_qseq, d_tseq, d_bt,
-		                  d_status, d_score, K, stream);
+		                  d_status, d_score, K, stream, fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
 	if (!ids[GD_KIND_GENERIC].empty()) {
 		const size_t lds = (size_t)max_cap * 7;
 		if (lds > 64 * 1024)

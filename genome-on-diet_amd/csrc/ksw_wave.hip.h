@@ -196,7 +196,8 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *_
                                                                 const uint8_t *__restrict__ qseq,
                                                                 const uint8_t *__restrict__ tseq,
                                                                 uint8_t *__restrict__ bt, int32_t *__restrict__ status,
-                                                                int32_t *__restrict__ score_out, WaveK K)
+                                                                int32_t *__restrict__ score_out, WaveK K,
+                                                                int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
 {
 	constexpr int NBLK = 128;
 	const int lane = threadIdx.x & 63;
@@ -283,16 +284,22 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *_
 		}
 		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
 	}
+	const bool fuse = cigar != nullptr; // walk the alignment back right away (see ksw_extd2_wave_kernel)
 	if (L0.blk == mlast || L1.blk == mlast) {
 		score_out[tid] = Rf >> 3;
-		status[tid] = GD_ST_DONE;
+		status[tid] = fuse ? GD_ST_TRACED : GD_ST_DONE;
+	}
+	if (fuse) {
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+		gd_bt_wave_walk(*Tp, tid, bt, n_cigar, cigar, lane);
 	}
 }
 
 static inline void gd_launch_wave128(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
-                                     uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s)
+                                     uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int32_t *n_cigar = nullptr,
+                                     uint32_t *cigar = nullptr)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	hipLaunchKernelGGL(ksw_extd2_wave128_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K);
+	hipLaunchKernelGGL(ksw_extd2_wave128_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 }
