@@ -238,3 +238,29 @@ def test_fresh_reads_match_host_emulator(gpu_ctx, pkg, host_emulator, kind, n, l
         assert mapped > 0.5 * n
     finally:
         m.close()
+
+
+def test_three_batches_in_flight_short_reads(gpu_ctx, pkg):
+    """gdiet_hip_set_inflight(3) with the ShortReads variant: three tickets open at once, several rounds, records identical to the
+    synchronous call; afterwards the depth can be changed back"""
+    from fixture_io import SR
+    names, seqs = read_fasta(os.path.join(SR, "ref.fa.gz"))
+    reads = reads_of("sr")
+    parts = [reads[0:700], reads[700:1300], reads[1300:2000]]
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset="sr")
+    try:
+        batches = [m.upload([r[1] for r in p]) for p in parts]
+        want = [m.sam_batch(m.map_uploaded(b), p) for b, p in zip(batches, parts)]
+        assert "".join(want) == "".join(l + "\n" for l in golden_sam("sr"))
+        m.set_inflight(3)
+        for _ in range(3):
+            tickets = [m.submit(b) for b in batches]
+            got = [m.sam_batch(m.wait(t), p) for t, p in zip(tickets, parts)]
+            assert got == want
+        m.set_inflight(2)
+        t = m.submit(batches[0])
+        assert m.sam_batch(m.wait(t), parts[0]) == want[0]
+        for b in batches:
+            m.free_batch(b)
+    finally:
+        m.close()
