@@ -159,7 +159,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="reads per step per GPU")
+    ap.add_argument("--batch", type=int, default=5120,
+                    help="reads per step per GPU (5120 reads = ~9 400 alignments: just under two rounds of the 5 120 resident wavefront slots; "
+                         "measured best of 4096..6144; its backtrace arena is 175 GB of the 288 GB)")
     ap.add_argument("--ref-mbp", type=float, default=float(os.environ.get("GDIET_BENCH_REF_MBP", "3088")),
                     help="size of the synthetic reference in Mbp (default: GRCh38-sized)")
     ap.add_argument("--lanes", type=int, default=1, help="software-pipeline depth inside a step (gdiet_hip_set_map_lanes)")
