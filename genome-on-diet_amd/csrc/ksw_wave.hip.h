@@ -165,16 +165,26 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 	}
 }
 
+static inline int gd_wave64_block()
+{
+	static int bs = 0;
+	if (!bs) { const char *e = getenv("GDIET_WAVE64_BLOCK"); bs = e ? atoi(e) : 64; if (bs != 64 && bs != 128 && bs != 256) bs = 64; }
+	return bs;
+}
+
 static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
                                     uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int tag = 0, bool single = false,
                                     int32_t *n_cigar = nullptr, uint32_t *cigar = nullptr /* both given: fused backtrack */)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0, false>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
-	else if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
-	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
-	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), dim3((n + 3) / 4), dim3(256), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	// one wavefront per workgroup: a finished wavefront frees its slot at once instead of waiting for its three block mates
+	const int bs = gd_wave64_block();
+	const dim3 grid((n + bs / 64 - 1) / (bs / 64)), block(bs);
+	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0, false>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 }
 // ids: 4 task ids per wavefront (identical geometry; -1 pads an incomplete quartet), n_quartets wavefronts
 static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, int n_quartets, const uint8_t *q, const uint8_t *t,
