@@ -39,6 +39,7 @@ struct gdiet_ctx {
 	hipStream_t stream_dp = nullptr;   // stream of the DP stage in an async lane (GDIET_DP_PRIORITY=1 raises its priority)
 	hipEvent_t ev2[3] = {nullptr, nullptr, nullptr}; // go, DP of the tail done, tail done
 	int dp_split = 1, wave_slots = 5120, last_split = 0;
+	int wide_two_waves = -1;           // GDIET_WIDE_TWO_WAVES: 1 / 0 force the two-wavefront / two-blocks-per-lane kernel for wide bands, default by count
 	int vote_wave = 1;                 // GDIET_VOTE_WAVE=0: the sequential vote kernel for long reads too
 	int index_on_device = 1;           // GDIET_INDEX_BUILD=host: gdiet_hip_index_build sketches and sorts on host threads instead
 	int fuse_bt = 1;                   // GDIET_FUSE_BT=0: the 64-lane kernel leaves the backtrack to the separate kernel
@@ -151,6 +152,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (sl && atoi(sl) > 0) ctx->slices_per_lane = atoi(sl);
 		const char *bw = getenv("GDIET_BT_WAVE");
 		if (bw) ctx->bt_wave = atoi(bw) != 0;
+		const char *tw = getenv("GDIET_WIDE_TWO_WAVES");
+		if (tw) ctx->wide_two_waves = atoi(tw) != 0;
 		const char *vw = getenv("GDIET_VOTE_WAVE");
 		if (vw) ctx->vote_wave = atoi(vw) != 0;
 		const char *ib = getenv("GDIET_INDEX_BUILD");
@@ -450,9 +453,18 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	if (!ids[GD_KIND_WAVE16].empty())
 		gd_launch_wave16(d_tasks, d_ids + id_off[GD_KIND_WAVE16], (int)(quartets.size() / 4), d_qseq, d_tseq, d_bt,
 		                 d_status, d_score, K, stream, single);
-	if (!ids[GD_KIND_WAVE128].empty())
-		gd_launch_wave128(d_tasks, d_ids + id_off[GD_KIND_WAVE128], (int)ids[GD_KIND_WAVE128].size(), d_qseq, d_tseq, d_bt,
-		                  d_status, d_score, K, stream, fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
+	if (!ids[GD_KIND_WAVE128].empty()) {
+		// few wide-band alignments (the arena bounds how many 50 kbp ONT alignments fit): two wavefronts share one, halving the
+		// serial chain; plenty of them: one wavefront each, two blocks per lane, no barrier
+		const int n128 = (int)ids[GD_KIND_WAVE128].size();
+		const bool two = ctx->wide_two_waves == 1 || (ctx->wide_two_waves < 0 && n128 < ctx->wave_slots / 2);
+		if (two)
+			gd_launch_wave2x64(d_tasks, d_ids + id_off[GD_KIND_WAVE128], n128, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream,
+			                   fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
+		else
+			gd_launch_wave128(d_tasks, d_ids + id_off[GD_KIND_WAVE128], n128, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream,
+			                  fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
+	}
 	if (!ids[GD_KIND_GENERIC].empty()) {
 		const size_t lds = (size_t)max_cap * 7;
 		if (lds > 64 * 1024)

@@ -313,3 +313,113 @@ static inline void gd_launch_wave128(const KswTask *tasks, const int32_t *ids, i
 	gdw_make_consts(C, K);
 	hipLaunchKernelGGL(ksw_extd2_wave128_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 }
+
+// ---- wide bands, few alignments: TWO wavefronts per alignment ----------------------------------------------------------------
+// 50 kbp ONT alignments hold 134 MB of backtrace each, so only ~1 500 fit the arena at once: fewer than the GPU has wavefront
+// slots, and the kernel time is the serial chain of the longest one.  Here a workgroup of two wavefronts shares one alignment:
+// block position p = blk mod 128 lives in wavefront p >> 6, lane p & 63 (one block per lane, as in the 64-lane kernel), so the
+// chain per anti-diagonal is half as long as in the two-blocks-per-lane form.  Inside a wavefront the t-1 neighbour comes through
+// DPP as before; lane 0 takes it from lane 63 of the other wavefront through LDS (double-buffered by the parity of the row: one
+// workgroup barrier per anti-diagonal).  Backtrace layout and results are those of ksw_extd2_wave128_kernel.
+__global__ __launch_bounds__(128) void ksw_extd2_wave2x64_kernel(const KswTask *__restrict__ tasks,
+                                                                 const int32_t *__restrict__ task_ids, int n_tasks,
+                                                                 const uint8_t *__restrict__ qseq,
+                                                                 const uint8_t *__restrict__ tseq,
+                                                                 uint8_t *__restrict__ bt, int32_t *__restrict__ status,
+                                                                 int32_t *__restrict__ score_out, WaveK K,
+                                                                 int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
+{
+	constexpr int NBLK = 128;
+	__shared__ u32 xch[2][2][8]; // [row parity][wavefront]: X[7], V[7], X2[7], Qc[3] of lane 63, and the tracker hand-off
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int slot = blockIdx.x;
+	if (slot >= n_tasks) return;
+	const int tid = __builtin_amdgcn_readfirstlane(task_ids[slot]);
+	if (__builtin_amdgcn_readfirstlane(status[tid]) != GD_ST_PENDING) return;
+	const KswTask *Tp = tasks + tid;
+	const int qlen = __builtin_amdgcn_readfirstlane(Tp->qlen), tlen = __builtin_amdgcn_readfirstlane(Tp->tlen);
+	int w = __builtin_amdgcn_readfirstlane(Tp->w);
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const uint8_t *query = qseq + Tp->qoff, *target = tseq + Tp->toff;
+	uint8_t *p = bt + Tp->bt_off;
+	const size_t row_bytes = (size_t)__builtin_amdgcn_readfirstlane(Tp->row_bytes);
+	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+
+	WaveLane L;
+	gdw_load_block(L, K, wv * 64 + lane, 0, query, qlen, target, tlen);
+	bool any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0;
+	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
+	for (int r = 0; r <= rend; ++r) {
+		WaveRow W;
+		W.r = r;
+		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+		const int advanced = W.st_ > prev_st_;
+		W.use_array = advanced;
+		W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
+		W.set_tr = (W.en0 | 15) >= r;
+		W.ukey = gdw_edge_key(K, r);
+		// (1) row r-1 values of the block below: DPP inside the wavefront, LDS across the two
+		u32 pX = gdw_ror1<64>(L.X[7]), pV = gdw_ror1<64>(L.V[7]), pX2 = gdw_ror1<64>(L.X2[7]), pQ = gdw_ror1<64>(L.Qc[3]);
+		u32 *mine = xch[r & 1][wv];
+		const u32 *other = xch[r & 1][wv ^ 1];
+		if (lane == 63) mine[0] = L.X[7], mine[1] = L.V[7], mine[2] = L.X2[7], mine[3] = L.Qc[3];
+		__syncthreads();
+		if (lane == 0) pX = other[0], pV = other[1], pX2 = other[2], pQ = other[3];
+		// (2) query window advance; the lane whose block fell below the window takes over block +128
+		if (r > 0) gdw_shift_query(L, pQ, L.blk == prev_st_, gdw_seam_byte(query, qlen, r - (prev_st_ << 4)));
+		if (advanced) {
+			if (L.blk < W.st_) gdw_load_block(L, K, L.blk + NBLK, r, query, qlen, target, tlen);
+			any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0;
+		}
+		// (3) scalar fix-ups and the score row
+		if (W.set_tr) gdw_reset_tr(L, K, W);
+		if (W.st0 != prev_st0 || W.up != prev_up || advanced) gdw_make_sel(L, W.st0, W.up);
+		gdw_update_scores(L, K, any_tn);
+		// (4) DP cells of the lanes inside the reference's 16-aligned window
+		if (L.blk <= W.en_) {
+			u32 out[4];
+			gdw_compute<true>(L, K, W, pX, pV, pX2, out);
+			*reinterpret_cast<uint4 *>(p + (size_t)r * row_bytes + ((L.blk - W.st_) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+		}
+		// (5) score trackers
+		if (r == 0) L.R = gdw_lo(L.V[0]) - K.B1 - K.qe8;
+		else L.R += gdw_lo(L.V[0]) - K.B1;
+		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 15) == 0) { // uniform over the workgroup: a block enters the band
+			const int ho = gdw_track_handoff(L);
+			int h = (int)gdw_ror1<64>((u32)ho);
+			if (lane == 63) mine[4] = (u32)ho;
+			__syncthreads();
+			if (lane == 0) h = (int)other[4];
+			if (L.blk == W.en_) L.R = h + gdw_lo(L.U[0]);
+		}
+		if (W.en0 == tlen - 1) {
+			if (L.blk == mlast) {
+				if (!have_f) Rf = gdw_track_to_slot(L, sl);
+				else Rf += gdw_cell(L.V, sl) - K.B1;
+			}
+			have_f = 1;
+		}
+		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
+	}
+	const bool fuse = cigar != nullptr;
+	if (L.blk == mlast) {
+		score_out[tid] = Rf >> 3;
+		status[tid] = fuse ? GD_ST_TRACED : GD_ST_DONE;
+	}
+	if (fuse) { // one of the two wavefronts walks the alignment back, once both have stored their last rows
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+		__syncthreads();
+		if (wv == 0) gd_bt_wave_walk(*Tp, tid, bt, n_cigar, cigar, lane);
+	}
+}
+
+static inline void gd_launch_wave2x64(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
+                                      uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int32_t *n_cigar = nullptr,
+                                      uint32_t *cigar = nullptr)
+{
+	WaveK K;
+	gdw_make_consts(C, K);
+	hipLaunchKernelGGL(ksw_extd2_wave2x64_kernel, dim3(n), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+}

@@ -207,3 +207,32 @@ def test_error_behaviour_of_the_abi(gpu_ctx, pkg):
     assert lib.gdiet_hip_ksw_extd2_batch(None, 1, None, None, None, None, None, None, None, None, None, None, None) == -3
     ctx2 = C.c_void_p()
     assert lib.gdiet_hip_init(C.byref(ctx2), 99) == -1  # no such device: GDIET_E_NODEVICE
+
+
+@pytest.mark.parametrize("two_waves", ["0", "1"])
+def test_wide_band_kernels_match_oracle(pkg, oracle, monkeypatch, two_waves):
+    """ONT bands (w = 1300: more than 64 blocks in flight) on both wide-band kernels -- two blocks per lane in one wavefront,
+    and two wavefronts per alignment exchanging their boundary through LDS -- against the oracle"""
+    gdo, lib = oracle
+    monkeypatch.setenv("GDIET_WIDE_TWO_WAVES", two_waves)
+    ctx = pkg.Context(0)
+    try:
+        rng = np.random.default_rng(40 + int(two_waves))
+        qs, ts, ws = [], [], []
+        for i in range(24):
+            n = int(rng.integers(1400, 5000))
+            q, t = gdo.make_pair(rng, n, 0.03, 0.02, 0.02, n_frac=0.01 if i % 5 == 0 else 0.0)
+            if i % 4 == 1:
+                q = q.copy()
+                q[q == 4] = 7  # N of a reverse-complemented read
+            qs.append(q), ts.append(t), ws.append(1300 if i % 3 else int(rng.integers(1050, 1900)))
+        sc, cg = ctx.ksw_extd2_batch(qs, ts, ws, pkg.KswScore.from_preset("ont"))
+        assert ctx.last_kernel_mask() & 8
+        a, b, q_, e, q2, e2 = gdo.PRESETS["ont"]
+        mat = gdo.score_matrix(a, b)
+        for i in range(len(qs)):
+            o = gdo.oracle_extd2(lib, qs[i], ts[i], mat, q_, e, q2, e2, ws[i], flag=gdo.EZ_APPROX_MAX | gdo.EZ_AVX512_SC)
+            assert sc[i] == o["score"], (i, len(qs[i]), len(ts[i]), ws[i], sc[i], o["score"])
+            assert np.array_equal(cg[i], o["cigar"]), (i, len(qs[i]), len(ts[i]), ws[i])
+    finally:
+        ctx.close()
