@@ -304,7 +304,8 @@ static int gd_consts(gdiet_ctx *ctx, const gdiet_ksw_score_t *sc, KswConst &K)
 static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const uint8_t *d_tseq, const int32_t *d_exact_score,
                             const gdiet_ksw_score_t *sc, int32_t *d_score, int32_t *d_n_cigar, uint32_t *d_cigar, const int64_t *d_cigar_off,
                             const int64_t *h_qoff, const int64_t *h_toff, const int32_t *h_w, void *stream_, const int64_t *h_cigar_off,
-                            const int32_t *h_exact_score, hipEvent_t arena_free = nullptr /* the kernels (not the descriptor copies) wait for it */)
+                            const int32_t *h_exact_score, hipEvent_t arena_free = nullptr /* the kernels (not the descriptor copies) wait for it */,
+                            std::unique_lock<std::mutex> *arena_turn = nullptr /* locked here once the planning is done, left locked */)
 {
 	if (!ctx) return GDIET_E_PARAM;
 	if (n <= 0) return GDIET_OK;
@@ -368,14 +369,22 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		ids[T.kind].push_back(i);
 		ctx->last_mask |= T.kind == GD_KIND_GENERIC ? 2 : T.kind == GD_KIND_WAVE16 ? 4 : T.kind == GD_KIND_WAVE128 ? 8 : 1;
 	}
-	// longest alignments first inside each class: the tail of the grid is then made of short jobs
-	for (int k = 0; k < 4; ++k)
+	// longest alignments first inside each class: the tail of the grid is then made of short jobs (a class whose members all have
+	// one geometry -- a short-read batch -- is in order already)
+	for (int k = 0; k < 4; ++k) {
+		bool uniform = true;
+		for (size_t j = 1; j < ids[k].size() && uniform; ++j) {
+			const KswTask &A = ctx->h_tasks[ids[k][0]], &B = ctx->h_tasks[ids[k][j]];
+			uniform = A.qlen == B.qlen && A.tlen == B.tlen && A.w == B.w;
+		}
+		if (uniform) continue;
 		std::stable_sort(ids[k].begin(), ids[k].end(), [&](int a, int b) {
 			const KswTask &A = ctx->h_tasks[a], &B = ctx->h_tasks[b];
 			if ((int64_t)A.qlen + A.tlen != (int64_t)B.qlen + B.tlen) return (int64_t)A.qlen + A.tlen > (int64_t)B.qlen + B.tlen;
 			if (A.qlen != B.qlen) return A.qlen > B.qlen; // equal geometries become neighbours (16-lane quartets below)
 			return A.w > B.w;
 		});
+	}
 	// the 16-lane kernel runs four alignments of identical (qlen, tlen, w) per wavefront: cut the sorted list into quartets
 	// (-1 pads an incomplete one)
 	std::vector<int32_t> quartets;
@@ -403,6 +412,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	}
 	ctx->last_cells = cells_sum, ctx->last_alg_bytes = alg_sum;
 	DevBuf &arena = ctx->parent ? ctx->parent->arena : ctx->arena; // an async lane works in its parent's arena (behind parent->arena_ev)
+	if (arena_turn) arena_turn->lock(); // everything above was this batch's own planning: only the use of the arena is ordered
 	if (ctx->parent && bt > arena.cap) GD_HIP(hipEventSynchronize(ctx->parent->arena_ev)); // growing it: the previous user must be done
 	if ((rc = gd_grow(ctx, arena, bt))) return rc;
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;

@@ -500,14 +500,15 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			sd = ctx->stream_dp;
 			GD_HIP(hipEventRecord(ctx->gather_ev, s)); // windows gathered (and everything else queued on s)
 			GD_HIP(hipStreamWaitEvent(sd, ctx->gather_ev, 0));
-			dp_lock = std::unique_lock<std::mutex>(ctx->parent->dp_mu);
+			dp_lock = std::unique_lock<std::mutex>(ctx->parent->dp_mu, std::defer_lock); // taken inside, after the planning
 		}
 		rc = gd_ksw_batch_dev(ctx, nb, (const uint8_t *)ctx->m_q.p, (const uint8_t *)ctx->m_t.p, d_ex, &ks, d_score, d_ncig, (uint32_t *)ctx->m_cig.p, d_coff,
-		                      qoff.data(), toff.data(), bw.data(), sd, coff.data(), ex.data(), ctx->parent ? ctx->parent->arena_ev : nullptr);
-		if (rc) return rc;
+		                      qoff.data(), toff.data(), bw.data(), sd, coff.data(), ex.data(), ctx->parent ? ctx->parent->arena_ev : nullptr,
+		                      ctx->parent ? &dp_lock : nullptr);
+		if (rc) return rc; // (the lock, if taken, is released by dp_lock's destructor)
 		if (ctx->parent) {
 			GD_HIP(hipEventRecord(ctx->parent->arena_ev, sd)); // the backtrack is done by then: the CIGARs sit in this lane's own buffer
-			dp_lock.unlock();
+			if (dp_lock.owns_lock()) dp_lock.unlock();
 		}
 		GD_HIP(hipMemcpyAsync(h_score.data(), d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipMemcpyAsync(h_ncig.data(), d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
