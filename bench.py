@@ -154,6 +154,27 @@ def cpu_baseline_port(reads_enc, budget_s=12.0):
             "sample": "%d full-read candidate alignments (%d bases): DP + backtrack stage of the oracle port only, 1 thread" % (n, bases)}
 
 
+def self_check(res, res_again, reads):
+    n = len(reads)
+    same, cig_ok, placed, mapped = True, 0, 0, 0
+    for i in range(n):
+        nr = res.n_regs[i]
+        same &= nr == res_again.n_regs[i]
+        if nr <= 0:
+            continue
+        mapped += 1
+        for j in range(nr):
+            a, b = res.regs[i][j], res_again.regs[i][j]
+            same &= (a.rid, a.rs, a.re, a.qs, a.qe, a.score, a.mapq, a.n_cigar) == (b.rid, b.rs, b.re, b.qs, b.qe, b.score, b.mapq, b.n_cigar)
+        r = res.regs[i][0]
+        cg = np.ctypeslib.as_array(r.cigar, shape=(r.n_cigar,))
+        ops, lens = cg & 0xf, cg >> 4
+        cig_ok += int(lens[(ops == 0) | (ops == 1)].sum() == r.qe - r.qs and lens[(ops == 0) | (ops == 2)].sum() == r.re - r.rs)
+        _, c, st = reads[i][0].split("_")
+        placed += int(r.rid == int(c[1:]) - 1 and abs(r.rs - int(st)) < 2000)
+    return {"reads": n, "mapped": mapped, "pipelined_equals_synchronous": bool(same), "cigar_spans_consistent": cig_ok, "primary_at_true_origin": placed}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +258,10 @@ def main():
     mapper.set_lanes(1)
     res1 = mapper.map_uploaded(batch)
     dp_alone = ctx.last_kernel_ms()[0]
+    # size-independent self-checks at full size (outside the timed region): the pipelined steps and this synchronous pass give the
+    # same records (idempotence); every CIGAR consumes exactly its query and reference interval; the primary record of a mapped
+    # read lies where the read was drawn from (the read names carry contig and start)
+    check = self_check(res, res1, reads)
     del res1
 
     mapped = np.array([res.n_regs[i] > 0 for i in range(len(reads))])
@@ -284,7 +309,7 @@ def main():
                        "stage_s_per_step": {"seed_kernel": st[0], "vote_kernel": st[1], "host_geometry": st[2], "gather_dp_backtrack": st[3],
                                             "host_postprocess": st[4], "other": st[5]},
                        "p50_read_latency_note": "every read of a batch completes with its batch; with 2 batches in flight a batch takes ~2 x ms_per_step from submit to wait",
-                       "batches_in_flight": args.inflight,
+                       "batches_in_flight": args.inflight, "self_check": check,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": cores, "pipeline_lanes": args.lanes},
             "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave_kernel<64, 0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(alg), "dp_cells_per_launch": int(cells), "gcups": cells / (dp * 1e-3) / 1e9, "kernel_ms": dp,
