@@ -57,6 +57,8 @@ struct gdiet_ctx {
 	std::mutex dp_mu;                  // orders the lanes' DP stages: held while one ENQUEUES its stage behind arena_ev
 	hipEvent_t gather_ev = nullptr;    // this lane's windows are gathered (its DP stream waits for it)
 	hipEvent_t arena_ev = nullptr;     // recorded after the last DP stage that was enqueued: the arena is free once it has completed
+	size_t lane_arena_cap = 0;         // a lane whose batch needs no more backtrace than this works in an arena of its own (set with the depth)
+	bool own_arena = false;            // (lane) the last DP stage did
 	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool async_busy[4] = {false, false, false, false};
 	int async_next = 0, async_depth = 2;
@@ -102,6 +104,7 @@ static int gd_grow(gdiet_ctx *ctx, DevBuf &b, size_t bytes)
 		return GDIET_E_NOMEM;
 	}
 	b.cap = want;
+	if (getenv("GDIET_TRACE_ALLOC")) fprintf(stderr, "[gdiet] device buffer grown to %zu bytes\n", want);
 	return GDIET_OK;
 }
 
@@ -411,9 +414,20 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
 	}
 	ctx->last_cells = cells_sum, ctx->last_alg_bytes = alg_sum;
-	DevBuf &arena = ctx->parent ? ctx->parent->arena : ctx->arena; // an async lane works in its parent's arena (behind parent->arena_ev)
+	// An async lane works in its parent's arena, taking turns behind parent->arena_ev -- unless the batch's backtrace is small
+	// enough for every lane in flight to hold one of its own (long-read batches of few reads: their DP kernels then overlap, which
+	// fills the GPU while one batch's longest alignments are still running).
+	bool own = ctx->parent && bt <= ctx->parent->lane_arena_cap;
+	if (own && bt > ctx->arena.cap) { // grown in big steps: freeing device memory stalls every lane
+		const size_t want = std::min(ctx->parent->lane_arena_cap, std::max<size_t>(bt * 2, (size_t)1 << 30));
+		if (gd_grow(ctx, ctx->arena, std::max(bt, want - (want >> 3) - 4096)) && gd_grow(ctx, ctx->arena, bt)) own = false, ctx->err.clear(); // no room: take turns in the shared one
+	}
+	if (ctx->parent && !own && ctx->arena.p) { (void)hipFree(ctx->arena.p); ctx->arena.p = nullptr, ctx->arena.cap = 0; }
+	ctx->own_arena = own;
+	if (own) arena_free = nullptr, arena_turn = nullptr;
+	DevBuf &arena = ctx->parent && !own ? ctx->parent->arena : ctx->arena;
 	if (arena_turn) arena_turn->lock(); // everything above was this batch's own planning: only the use of the arena is ordered
-	if (ctx->parent && bt > arena.cap) GD_HIP(hipEventSynchronize(ctx->parent->arena_ev)); // growing it: the previous user must be done
+	if (ctx->parent && !own && bt > arena.cap) GD_HIP(hipEventSynchronize(ctx->parent->arena_ev)); // growing it: the previous user must be done
 	if ((rc = gd_grow(ctx, arena, bt))) return rc;
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * ctx->h_ids.size()))) return rc;

@@ -507,7 +507,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		                      ctx->parent ? &dp_lock : nullptr);
 		if (rc) return rc; // (the lock, if taken, is released by dp_lock's destructor)
 		if (ctx->parent) {
-			GD_HIP(hipEventRecord(ctx->parent->arena_ev, sd)); // the backtrack is done by then: the CIGARs sit in this lane's own buffer
+			if (!ctx->own_arena) GD_HIP(hipEventRecord(ctx->parent->arena_ev, sd)); // the backtrack is done by then: the CIGARs sit in this lane's own buffer
 			if (dp_lock.owns_lock()) dp_lock.unlock();
 		}
 		GD_HIP(hipMemcpyAsync(h_score.data(), d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
@@ -649,6 +649,12 @@ extern "C" int gdiet_hip_set_inflight(gdiet_ctx *ctx, int n)
 	for (int i = 0; i < GD_MAX_INFLIGHT; ++i) if (ctx->async_busy[i]) { ctx->err = "batches are in flight"; return GDIET_E_PARAM; }
 	gd_drop_async_lanes(ctx);
 	ctx->async_depth = n, ctx->async_next = 0;
+	// private backtrace arenas for the lanes when all of them fit beside the index and the batches' own buffers
+	size_t free_b = 0, total_b = 0;
+	(void)hipSetDevice(ctx->device);
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError(), total_b = 0;
+	ctx->lane_arena_cap = n > 1 ? (size_t)((double)total_b * 0.70 / n) : 0;
+	if (const char *e = getenv("GDIET_LANE_ARENA_GB")) ctx->lane_arena_cap = (size_t)(atof(e) * 1e9);
 	return GDIET_OK;
 }
 

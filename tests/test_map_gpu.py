@@ -260,6 +260,14 @@ def test_three_batches_in_flight_short_reads(gpu_ctx, pkg):
         m.set_inflight(2)
         t = m.submit(batches[0])
         assert m.sam_batch(m.wait(t), parts[0]) == want[0]
+        # small batches: every lane had a backtrace arena of its own above; now the lanes take turns in the shared one
+        os.environ["GDIET_LANE_ARENA_GB"] = "0"
+        try:
+            m.set_inflight(3)
+        finally:
+            del os.environ["GDIET_LANE_ARENA_GB"]
+        tickets = [m.submit(b) for b in batches]
+        assert [m.sam_batch(m.wait(t), p) for t, p in zip(tickets, parts)] == want
         for b in batches:
             m.free_batch(b)
     finally:

@@ -3,7 +3,7 @@
 Not the headline bench (bench.py = configs[3]); same structure, smaller synthetic reference by default.
 
     python tools/bench_variant.py --kind sr  [--batch 262144] [--ref-mbp 400] [--steps 5]
-    python tools/bench_variant.py --kind ont [--batch 256]    [--ref-mbp 400] [--steps 3]
+    python tools/bench_variant.py --kind ont [--batch 512] [--inflight 3] [--ref-mbp 400] [--steps 8]
 """
 import argparse
 import json
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--inflight", type=int, default=1)
     a = ap.parse_args()
-    n = a.batch or (262144 if a.kind == "sr" else 256)
+    n = a.batch or (262144 if a.kind == "sr" else 512)
     pkg = _load_pkg()
     ctx = pkg.Context(0)
     names, contigs = bench.synth_reference(a.ref_mbp, seed=2)
