@@ -105,7 +105,7 @@ def cpu_baseline_reference(names, contigs, rng, cores, budget_s=25.0):
     """the reference's own GDiet_avx on the host: index the smallest contig with -d, then time mapping only"""
     exe = os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")
     c = int(np.argmin([len(x) for x in contigs]))
-    reads = synth_hifi_reads(rng, contigs, min(2048, max(256, 8 * cores)), only_contig=c)
+    reads = synth_hifi_reads(rng, contigs, 2048, only_contig=c)  # ~31 Mbases: seconds of wall time on the host's cores
     hifi = ("-ax map-hifi -Z 10 -W 2 -i 0.2 -k 19 -w 19 -N 1 -r 1000 --vt_dis=650 --vt_nb_loc=5 --vt_df1=0.0106 --vt_df2=0.2 -s 400 "
             "--vt_cov 0.04 --max_min_gap=4000 --vt_f=0.04 --sort=merge --frag=no -F200,1 --secondary=yes -a").split()
     with tempfile.TemporaryDirectory() as d:
@@ -116,10 +116,11 @@ def cpu_baseline_reference(names, contigs, rng, cores, budget_s=25.0):
             for nm, s in reads:
                 f.write(b"@" + nm.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
         subprocess.run([exe, "-t", str(cores)] + hifi + ["-d", mmi, fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-        # the reference's thread scaling is poor on many-core hosts (its per-alignment 30 MB backtrace allocations serialise in the
-        # kernel), so the baseline is the BEST of a few thread counts on the same sample, not simply -t <all cores>
+        # `cores` = the CPUs this container may use (cgroup quota / affinity, not the host's thread count).  The reference's thread
+        # scaling is not perfect (its per-alignment 30 MB backtrace allocations serialise in the kernel), so the baseline is the BEST
+        # of a few thread counts on the same sample, not simply -t <all cores>
         best, tried = None, []
-        for t in sorted({min(cores, 8), min(cores, 32), cores}):
+        for t in sorted({max(1, cores // 2), cores, 2 * cores}):
             r = subprocess.run([exe, "-t", str(t)] + hifi + [mmi, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             err = r.stderr.decode(errors="ignore")
             m = re.search(r"\[M::main::([0-9.]+)\*[0-9.]+\] loaded/built the index", err)
@@ -189,6 +190,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight (gdiet_hip_map_submit/_wait): 2 overlaps the seeding/voting/host stages of step i+1 with the DP kernel of step i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads of the post-processing pool (default: the CPUs this container may use / ranks)")
     args = ap.parse_args()
 
     import torch
@@ -200,10 +202,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cores = max(1, (os.cpu_count() or 8) // max(1, world))
 
     from __graft_entry__ import _load_pkg
     pkg = _load_pkg()
+    pkg_cpus = pkg.effective_cpus()
+    cores = max(1, pkg_cpus // max(1, world))  # CPUs this container may use (cgroup quota, affinity), shared by the ranks of the node
     ctx = pkg.Context(local)
 
     t_setup = time.time()
@@ -211,7 +214,7 @@ def main():
     t_ref = time.time() - t_setup
     t1 = time.time()
     mapper = pkg.Mapper(ctx, names, contigs, preset="hifi", n_threads=cores)
-    mapper.set_host_threads(cores)  # N ranks on one node share its cores
+    mapper.set_host_threads(args.host_threads or cores)  # N ranks on one node share its cores
     t_index = time.time() - t1
     rng = np.random.default_rng(pkg.rank_seed(5, rank))  # HiFi reads seed 5 (+rank: read-sharded weak scaling)
     reads = synth_hifi_reads(rng, contigs, args.batch)
@@ -310,7 +313,7 @@ def main():
                                             "host_postprocess": st[4], "other": st[5]},
                        "p50_read_latency_note": "every read of a batch completes with its batch; with 2 batches in flight a batch takes ~2 x ms_per_step from submit to wait",
                        "batches_in_flight": args.inflight, "self_check": check,
-                       "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": cores, "pipeline_lanes": args.lanes},
+                       "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": args.host_threads or cores, "pipeline_lanes": args.lanes},
             "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave_kernel<64, 0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(alg), "dp_cells_per_launch": int(cells), "gcups": cells / (dp * 1e-3) / 1e9, "kernel_ms": dp,
                          "kernel_ms_note": "mean over the K timed launches (HIP events on each launch's stream); the 64-lane kernel walks its own "
@@ -322,7 +325,7 @@ def main():
             try:  # the reference binary itself where it travelled with the repo (and runs on this host's CPU) ...
                 if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")):
                     raise FileNotFoundError("oracle/_ref/gdiet_lr_avx")
-                out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), os.cpu_count() or 8)
+                out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), pkg_cpus)
             except Exception as ex:  # ... else the DP stage of the oracle port; the baseline must never take the benchmark line down
                 try:
                     out["cpu_baseline"] = cpu_baseline_port(port_reads)

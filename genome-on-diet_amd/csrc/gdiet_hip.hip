@@ -11,6 +11,9 @@
 #include <condition_variable>
 #include <functional>
 #include <atomic>
+#include <deque>
+#include <memory>
+#include <sched.h>
 
 #include "../../include/gdiet_hip.h"
 #include "ksw_common.h"
@@ -108,6 +111,30 @@ static int gd_grow(gdiet_ctx *ctx, DevBuf &b, size_t bytes)
 	return GDIET_OK;
 }
 
+// CPUs this process may really use: the smallest of the hardware count, the affinity mask and the cgroup CPU quota (a container
+// with a 16-CPU quota on a 256-thread host must not run 256 workers: they are throttled together every scheduling period)
+static int gd_effective_cpus()
+{
+	int n = (int)std::max(1u, std::thread::hardware_concurrency());
+	cpu_set_t set;
+	CPU_ZERO(&set);
+	if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = std::min(n, CPU_COUNT(&set));
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
+		char q[64];
+		long long period = 0;
+		if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") && period > 0) n = std::min<long long>(n, std::max<long long>(1, (atoll(q) + period - 1) / period));
+		fclose(f);
+	} else {
+		long long quota = -1, period = 0;
+		if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+		if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+		if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+	}
+	return n;
+}
+
+extern "C" int gdiet_hip_effective_cpus(void) { return gd_effective_cpus(); }
+
 extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 {
 	if (!out) return GDIET_E_PARAM;
@@ -147,7 +174,7 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (hipEventCreate(&ctx->ev2[i]) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
 	if (hipEventCreateWithFlags(&ctx->arena_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->gather_ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return GDIET_E_HIP; }
 	ctx->wave_slots = prop.multiProcessorCount * 4 * 5; // CUs x SIMDs x resident wavefronts of the 64-lane DP kernel (94 VGPRs)
-	ctx->host_threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+	ctx->host_threads = std::min(64, gd_effective_cpus());
 	{
 		const char *e = getenv("GDIET_SEED_KERNEL");
 		ctx->seed_thread_kernel = e && !strcmp(e, "thread") ? 1 : e && !strcmp(e, "wave") ? 2 : 0; // 0: by read length
@@ -344,6 +371,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	std::vector<int32_t> ids[4];
 	int max_cap = 0;
 	ctx->last_mask = 0;
+	struct { int qlen = -1, tlen = -1, w = 0; int32_t kind = 0, row_bytes = 0; } memo;
 	for (int i = 0; i < n; ++i) {
 		KswTask &T = ctx->h_tasks[i];
 		T.qoff = h_qoff[i], T.toff = h_toff[i];
@@ -353,7 +381,11 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		T.exact_score = d_exact_score ? h_ex[i] : GD_NEG_INF;
 		T.pad = 0;
 		if (T.qlen <= 0 || T.tlen <= 0) { ctx->err = "empty sequence in batch (the reference returns without aligning)"; return GDIET_E_PARAM; }
-		gd_plan_one(ctx->kernel_mode, wave_scoring_ok, T.qlen, T.tlen, T.w, T.kind, T.row_bytes);
+		if (T.qlen == memo.qlen && T.tlen == memo.tlen && T.w == memo.w) T.kind = memo.kind, T.row_bytes = memo.row_bytes;
+		else { // (the admission test of the wave kernels walks the blocks of the band; short-read batches repeat a few geometries)
+			gd_plan_one(ctx->kernel_mode, wave_scoring_ok, T.qlen, T.tlen, T.w, T.kind, T.row_bytes);
+			memo.qlen = T.qlen, memo.tlen = T.tlen, memo.w = T.w, memo.kind = T.kind, memo.row_bytes = T.row_bytes;
+		}
 		if (ctx->kernel_mode == 2 && T.kind == GD_KIND_GENERIC) { ctx->err = "alignment does not fit the wave kernel"; return GDIET_E_PARAM; }
 		if (T.kind == GD_KIND_GENERIC) {
 			int cap = gd_generic_cap(T.qlen, T.tlen, T.w);

@@ -31,46 +31,68 @@ struct gdiet_read_batch {
 
 #include "map_index_dev.hip.h"
 
-// Persistent host worker pool (one per context): the host stages of a batch are a few hundred microseconds of work per
-// thread, so creating the threads per call (tens of microseconds EACH, serialised) used to cost more than the work.
+// Persistent host worker pool.  The host stages of a batch are a few hundred microseconds of work per thread, so creating the
+// threads per call (tens of microseconds EACH, serialised) used to cost more than the work.  One pool serves a context AND its
+// async lanes (batches in flight): every parallel loop is a job in a shared FIFO, so a lane whose host stage runs alone gets all
+// the threads, several lanes' stages share them, and the number of running workers never exceeds the CPUs the process may use
+// (a static split -- threads / lanes each -- left most threads idle for long-read batches, whose host stages rarely coincide).
 struct GdPool {
+	struct Job {
+		std::function<void(int)> f;
+		int n = 0;
+		std::atomic<int> next{0}, done{0};
+		std::mutex mu;
+		std::condition_variable cv;
+	};
 	std::vector<std::thread> th;
 	std::mutex mu;
-	std::condition_variable cv_go, cv_done;
-	std::function<void(int)> job;
-	std::atomic<int> next{0};
-	int n = 0, gen = 0, active = 0, width = 0;
+	std::condition_variable cv_go;
+	std::deque<std::shared_ptr<Job>> jobs;
 	bool stop = false;
-	void worker(int id)
+	static void work_on(Job &J)
 	{
-		int seen = 0;
+		int mine = 0;
 		for (;;) {
+			const int i = J.next.fetch_add(16);
+			if (i >= J.n) break;
+			const int e = std::min(J.n, i + 16);
+			for (int j = i; j < e; ++j) J.f(j);
+			mine += e - i;
+		}
+		if (mine && J.done.fetch_add(mine) + mine == J.n) { std::unique_lock<std::mutex> lk(J.mu); J.cv.notify_all(); }
+	}
+	void worker()
+	{
+		for (;;) {
+			std::shared_ptr<Job> J;
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv_go.wait(lk, [&] { return stop || gen != seen; });
+				cv_go.wait(lk, [&] { return stop || !jobs.empty(); });
 				if (stop) return;
-				seen = gen;
-				if (id >= width) { if (--active == 0) cv_done.notify_one(); continue; }
+				J = jobs.front();
+				if (J->next.load() >= J->n) { jobs.pop_front(); continue; } // handed out completely: the next job's turn
 			}
-			for (;;) { const int i = next.fetch_add(16); if (i >= n) break; for (int j = i; j < std::min(n, i + 16); ++j) job(j); }
-			std::unique_lock<std::mutex> lk(mu);
-			if (--active == 0) cv_done.notify_one();
+			work_on(*J);
 		}
 	}
-	void ensure(int n_threads) { while ((int)th.size() < n_threads) { const int id = (int)th.size(); th.emplace_back([this, id] { worker(id); }); } }
 	template <class F> void run(int n_threads, int n_items, F f)
 	{
 		if (n_threads <= 1 || n_items < 32) { for (int i = 0; i < n_items; ++i) f(i); return; }
-		n_threads = std::min(n_threads, (n_items + 15) / 16);
-		ensure(n_threads - 1); // the caller works too
+		auto J = std::make_shared<Job>();
+		J->f = f, J->n = n_items;
 		{
 			std::unique_lock<std::mutex> lk(mu);
-			job = f, n = n_items, next = 0, width = n_threads - 1, active = (int)th.size(), ++gen;
+			while ((int)th.size() < n_threads - 1) th.emplace_back([this] { worker(); }); // the caller works too
+			jobs.push_back(J);
 		}
 		cv_go.notify_all();
-		for (;;) { const int i = next.fetch_add(16); if (i >= n_items) break; for (int j = i; j < std::min(n_items, i + 16); ++j) f(j); }
-		std::unique_lock<std::mutex> lk(mu);
-		cv_done.wait(lk, [&] { return active == 0; });
+		work_on(*J);
+		{
+			std::unique_lock<std::mutex> lk(J->mu);
+			J->cv.wait(lk, [&] { return J->done.load() == J->n; });
+		}
+		std::unique_lock<std::mutex> lk(mu); // (a worker may have dropped it already)
+		for (auto it = jobs.begin(); it != jobs.end(); ++it) if (it->get() == J.get()) { jobs.erase(it); break; }
 	}
 	~GdPool()
 	{
@@ -84,8 +106,13 @@ static void gd_pool_free(void *pool) { delete (GdPool *)pool; }
 
 static GdPool *gd_pool(gdiet_ctx *ctx)
 {
-	if (!ctx->pool) ctx->pool = new GdPool();
-	return (GdPool *)ctx->pool;
+	gdiet_ctx *owner = ctx->parent ? ctx->parent : ctx; // an async lane works in its parent's pool
+	if (!owner->pool) {
+		static std::mutex create_mu;
+		std::unique_lock<std::mutex> lk(create_mu);
+		if (!owner->pool) owner->pool = new GdPool();
+	}
+	return (GdPool *)owner->pool;
 }
 
 template <class F> static void gd_parallel_for(gdiet_ctx *ctx, int n_threads, int n, F f) { gd_pool(ctx)->run(n_threads, n, f); }
@@ -123,7 +150,7 @@ extern "C" int gdiet_hip_index_build(gdiet_ctx *ctx, gdiet_index **out, int n_se
 	std::vector<std::string> nm(n_seq);
 	std::vector<GdSeqSpan> sq(n_seq);
 	for (int i = 0; i < n_seq; ++i) nm[i] = names && names[i] ? names[i] : "", sq[i].p = seqs[i], sq[i].n = lens[i];
-	const int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+	const int nt = n_threads > 0 ? n_threads : gd_effective_cpus();
 	if (ctx->index_on_device) { // sketch, sort and table build on the GPU (map_index_dev.hip.h); GDIET_INDEX_BUILD=host selects the host builder
 		if (!gd_index_build_device(ix, nm, sq, k, w, P, nt, ctx->stream, ctx->err)) { gdiet_hip_index_destroy(ctx, ix); return GDIET_E_HIP; }
 		*out = ix;
@@ -278,14 +305,19 @@ static void gd_regs_out(const std::vector<GdReg> &v, int32_t *n_regs, gdiet_reg_
 	*n_regs = (int32_t)v.size();
 	*regs = nullptr;
 	if (v.empty()) return;
-	gdiet_reg_t *r = (gdiet_reg_t *)calloc(v.size(), sizeof(gdiet_reg_t));
+	// one allocation per read: the records, then their CIGARs (a batch of short reads is a million of these)
+	size_t words = 0;
+	for (const GdReg &g : v) words += g.cigar.size() + 1;
+	gdiet_reg_t *r = (gdiet_reg_t *)calloc(1, v.size() * sizeof(gdiet_reg_t) + words * 4);
+	uint32_t *cg = (uint32_t *)(r + v.size());
 	for (size_t i = 0; i < v.size(); ++i) {
 		const GdReg &g = v[i];
 		r[i].id = g.id, r[i].cnt = g.cnt, r[i].rid = g.rid, r[i].score = g.score, r[i].qs = g.qs, r[i].qe = g.qe, r[i].rs = g.rs, r[i].re = g.re;
 		r[i].parent = g.parent, r[i].subsc = g.subsc, r[i].mlen = g.mlen, r[i].blen = g.blen, r[i].mapq = g.mapq, r[i].rev = g.rev, r[i].sam_pri = g.sam_pri;
 		r[i].dp_score = g.dp_score, r[i].dp_max = g.dp_max, r[i].n_ambi = g.n_ambi, r[i].n_cigar = (uint32_t)g.cigar.size();
-		r[i].cigar = (uint32_t *)malloc(g.cigar.size() * 4 + 4);
-		if (!g.cigar.empty()) memcpy(r[i].cigar, g.cigar.data(), g.cigar.size() * 4);
+		r[i].cigar = cg;
+		if (!g.cigar.empty()) memcpy(cg, g.cigar.data(), g.cigar.size() * 4);
+		cg += g.cigar.size() + 1;
 	}
 	*regs = r;
 }
@@ -294,8 +326,7 @@ extern "C" void gdiet_hip_free_regs(int n, int32_t *n_regs, gdiet_reg_t **regs)
 {
 	if (!n_regs || !regs) return;
 	for (int i = 0; i < n; ++i) {
-		for (int j = 0; j < n_regs[i]; ++j) free(regs[i][j].cigar);
-		free(regs[i]);
+		free(regs[i]); // the CIGARs live in the same allocation
 		regs[i] = nullptr, n_regs[i] = 0;
 	}
 }
@@ -681,7 +712,7 @@ extern "C" int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *ix, const
 	}
 	gdiet_ctx *c = ctx->async_lane[l];
 	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves;
-	c->lane_threads = c->host_threads = std::max(1, ctx->host_threads / ctx->async_depth);
+	c->lane_threads = c->host_threads = ctx->host_threads; // all lanes draw from the parent's pool
 	ctx->async_busy[l] = true, ctx->async_next++;
 	t->lane = l;
 	t->th = std::thread([=]() {

@@ -29,6 +29,34 @@ def read_ranges_by_cost(lens, world, band=1000):
     return bounds
 
 
+def effective_cpus():
+    """CPUs this process may really use: min(os.cpu_count(), affinity mask, cgroup CPU quota).  A container with a 16-CPU quota on a
+    256-thread host reports 256 from os.cpu_count(); workers sized by that are throttled together every scheduling period."""
+    import math
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2
+            q, p = f.read().split()[:2]
+        if q != "max" and int(p) > 0:
+            n = min(n, max(1, math.ceil(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, math.ceil(q / p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def rank_seed(base_seed, rank):
     """weak scaling: every rank draws its own reads (same distribution, different stream)"""
     return base_seed + rank

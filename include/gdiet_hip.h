@@ -193,11 +193,12 @@ typedef struct {
 	uint32_t mapq, rev, sam_pri;
 	int32_t dp_score, dp_max;
 	uint32_t n_ambi, n_cigar;
-	uint32_t *cigar;              /* malloc'd by the library */
+	uint32_t *cigar;              /* points into the allocation of the record array it belongs to */
 } gdiet_reg_t;
 
 /* Map n_reads single-segment reads (ASCII sequences).  On return regs[i] is a malloc'd array of n_regs[i] records
- * (NULL when n_regs[i] == 0, as LR/map.c:1915), in the order mm_map_frag leaves them.  Free with gdiet_hip_free_regs. */
+ * (NULL when n_regs[i] == 0, as LR/map.c:1915), in the order mm_map_frag leaves them; the records' CIGARs live in the same
+ * allocation.  Free with gdiet_hip_free_regs only. */
 int gdiet_hip_map_batch(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, int n_reads,
                         const char *const *seqs, const int32_t *lens, int32_t *n_regs, gdiet_reg_t **regs);
 void gdiet_hip_free_regs(int n_reads, int32_t *n_regs, gdiet_reg_t **regs);
@@ -227,8 +228,11 @@ int gdiet_hip_map_stage_seconds(const gdiet_ctx *ctx, double out[6]);
  * chain on `n` independent lanes (stream + workspace + host threads each), overlapping the latency-bound stages of one slice
  * with the DP kernel of the others.  1 (default) = no pipelining.  Results do not depend on it. */
 int gdiet_hip_set_map_lanes(gdiet_ctx *ctx, int n);
-/* number of host threads used for geometry / CIGAR post-processing (default: hardware concurrency) */
+/* number of host threads used for geometry / CIGAR post-processing (default: gdiet_hip_effective_cpus(), at most 64) */
 int gdiet_hip_set_host_threads(gdiet_ctx *ctx, int n);
+/* CPUs the process may really use: min(hardware threads, affinity mask, cgroup CPU quota).  The reference sizes its worker pool
+ * with -t (LR/main.c:85 n_threads); a caller that derives -t from the machine should use this figure. */
+int gdiet_hip_effective_cpus(void);
 
 /* One SAM record exactly as mm_write_sam3 prints it for a single-segment read (LR/format.c:412-599); reg_idx < 0 writes
  * the unmapped record.  Returns the number of bytes needed (excluding the terminating NUL); writes at most cap bytes. */

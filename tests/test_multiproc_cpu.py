@@ -80,3 +80,16 @@ def test_cost_balanced_ranges():
         cost = (2 * lens - 1) * np.minimum(1001, lens)
         per = [int(cost[b[r]:b[r + 1]].sum()) for r in range(world)]
         assert max(per) - min(per) <= 2 * int(cost.max())
+
+
+def test_effective_cpus_respects_quota_and_affinity():
+    """the worker count is derived from what the container may use, not from the host's thread count; the library's C entry point
+    (gdiet_hip_effective_cpus) and the Python helper agree"""
+    import os
+    from conftest import load_pkg
+    pkg = load_pkg()
+    n = pkg.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert n <= len(os.sched_getaffinity(0))
+    lib = pkg.load_library()
+    assert lib.gdiet_hip_effective_cpus() == n

@@ -53,15 +53,16 @@ def main():
     ap.add_argument("--ref-mbp", type=float, default=400)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--inflight", type=int, default=1)
+    ap.add_argument("--host-threads", type=int, default=0)
     a = ap.parse_args()
     n = a.batch or (262144 if a.kind == "sr" else 512)
     pkg = _load_pkg()
     ctx = pkg.Context(0)
     names, contigs = bench.synth_reference(a.ref_mbp, seed=2)
     t0 = time.time()
-    m = pkg.Mapper(ctx, names, contigs, preset=a.kind, n_threads=os.cpu_count() or 8)
+    m = pkg.Mapper(ctx, names, contigs, preset=a.kind, n_threads=pkg.effective_cpus())
     t_idx = time.time() - t0
-    m.set_host_threads(min(256, os.cpu_count() or 8))
+    m.set_host_threads(a.host_threads or pkg.effective_cpus())
     reads = synth_reads(np.random.default_rng(7), contigs, n, a.kind)
     batch = m.upload(reads)
     bases = sum(len(r) for r in reads)
