@@ -300,23 +300,56 @@ extern "C" void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *b)
 	delete b;
 }
 
-static void gd_regs_out(const std::vector<GdReg> &v, int32_t *n_regs, gdiet_reg_t **regs)
+// Records leave the library in slabs of many reads each: a short-read batch has a quarter of a million reads, and an allocation
+// per read made the caller's gdiet_hip_free_regs the slowest stage of the pipeline.  Every host worker fills slabs of its own (a
+// read's records are written, and its temporaries released, by the thread that computed them), so no lock is involved.  Every
+// read's record array is preceded by a 16-byte GdRegHead; `head` marks the ones that start an allocation.
+struct GdRegHead { uint32_t magic, head; uint64_t pad; };
+static const uint32_t GD_REG_MAGIC = 0x67645247u;
+static const size_t GD_REG_SLAB = 1 << 20;
+
+static void *gd_reg_slab_take(uint64_t call_id, size_t bytes, bool &head)
+{
+	struct Cursor { uint64_t call = 0; char *p = nullptr; size_t left = 0; };
+	static thread_local Cursor C;
+	head = false;
+	if (C.call != call_id || C.left < bytes) { // what is left of the previous slab stays with its records
+		const size_t sz = std::max(bytes, GD_REG_SLAB);
+		char *m = (char *)malloc(sz);
+		if (!m) return nullptr;
+		C.call = call_id, C.p = m, C.left = sz, head = true;
+	}
+	void *at = C.p;
+	C.p += bytes, C.left -= bytes;
+	return at;
+}
+
+static size_t gd_regs_bytes(const std::vector<GdReg> &v)
+{
+	if (v.empty()) return 0;
+	size_t words = 0;
+	for (const GdReg &g : v) words += g.cigar.size() + 1;
+	return sizeof(GdRegHead) + v.size() * sizeof(gdiet_reg_t) + ((words * 4 + 7) & ~(size_t)7);
+}
+
+static void gd_regs_fill(const std::vector<GdReg> &v, void *at, bool head, int32_t *n_regs, gdiet_reg_t **regs)
 {
 	*n_regs = (int32_t)v.size();
 	*regs = nullptr;
 	if (v.empty()) return;
-	// one allocation per read: the records, then their CIGARs (a batch of short reads is a million of these)
-	size_t words = 0;
-	for (const GdReg &g : v) words += g.cigar.size() + 1;
-	gdiet_reg_t *r = (gdiet_reg_t *)calloc(1, v.size() * sizeof(gdiet_reg_t) + words * 4);
+	GdRegHead *h = (GdRegHead *)at;
+	h->magic = GD_REG_MAGIC, h->head = head ? 1 : 0, h->pad = 0;
+	gdiet_reg_t *r = (gdiet_reg_t *)(h + 1);
 	uint32_t *cg = (uint32_t *)(r + v.size());
 	for (size_t i = 0; i < v.size(); ++i) {
 		const GdReg &g = v[i];
+		memset(&r[i], 0, sizeof(r[i]));
 		r[i].id = g.id, r[i].cnt = g.cnt, r[i].rid = g.rid, r[i].score = g.score, r[i].qs = g.qs, r[i].qe = g.qe, r[i].rs = g.rs, r[i].re = g.re;
 		r[i].parent = g.parent, r[i].subsc = g.subsc, r[i].mlen = g.mlen, r[i].blen = g.blen, r[i].mapq = g.mapq, r[i].rev = g.rev, r[i].sam_pri = g.sam_pri;
 		r[i].dp_score = g.dp_score, r[i].dp_max = g.dp_max, r[i].n_ambi = g.n_ambi, r[i].n_cigar = (uint32_t)g.cigar.size();
 		r[i].cigar = cg;
 		if (!g.cigar.empty()) memcpy(cg, g.cigar.data(), g.cigar.size() * 4);
+		cg[g.cigar.size()] = 0;
 		cg += g.cigar.size() + 1;
 	}
 	*regs = r;
@@ -325,10 +358,15 @@ static void gd_regs_out(const std::vector<GdReg> &v, int32_t *n_regs, gdiet_reg_
 extern "C" void gdiet_hip_free_regs(int n, int32_t *n_regs, gdiet_reg_t **regs)
 {
 	if (!n_regs || !regs) return;
+	std::vector<void *> blocks; // freed after the scan: the other reads' heads live inside them
 	for (int i = 0; i < n; ++i) {
-		free(regs[i]); // the CIGARs live in the same allocation
+		if (regs[i]) {
+			GdRegHead *h = (GdRegHead *)regs[i] - 1;
+			if (h->magic == GD_REG_MAGIC && h->head) blocks.push_back(h);
+		}
 		regs[i] = nullptr, n_regs[i] = 0;
 	}
+	for (void *b : blocks) free(b);
 }
 
 static void gd_opt_from_c(const gdiet_mapopt_t *o, const gdiet_index *ix, GdMapOpt &O)
@@ -460,26 +498,33 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	ctx->stage_s[1] += gd_now() - t0, t0 = gd_now();
 	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
 	const GdRefView R = ix->h.ref();
-	std::vector<std::vector<GdCand>> cand(n);
+	// candidates of all reads in one flat array (capacity: what the vote kernel reported; the box stage may drop some).  Per-read
+	// vectors would be allocated by the workers and released by this thread -- a quarter of a million cross-thread frees per
+	// short-read batch, each contending for another thread's malloc arena.
+	std::vector<int> cfirst(n + 1, 0), ccount(n, 0);
+	for (int i = 0; i < n; ++i) cfirst[i + 1] = cfirst[i] + (int)reinterpret_cast<const MapVoteOut *>(vo_raw.get() + vo_head * (size_t)i)->n_cand;
+	std::vector<GdCand> cflat((size_t)cfirst[n]);
 	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
 		const MapVoteOut &vo_i = *reinterpret_cast<const MapVoteOut *>(vo_raw.get() + vo_head * (size_t)i); // head of the record only
 		const unsigned nc = vo_i.n_cand;
 		if (!nc) return;
-		cand[i].resize(nc);
-		for (unsigned j = 0; j < nc; ++j) cand[i][j].v = vo_i.cand[j];
-		if (is_sr) gd_sr_boxes(cand[i], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
-		else gd_lr_link_and_boxes(cand[i], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
+		std::vector<GdCand> C(nc);
+		for (unsigned j = 0; j < nc; ++j) C[j].v = vo_i.cand[j];
+		if (is_sr) gd_sr_boxes(C, O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
+		else gd_lr_link_and_boxes(C, O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
+		ccount[i] = (int)std::min<size_t>(C.size(), nc);
+		for (int j = 0; j < ccount[i]; ++j) cflat[(size_t)cfirst[i] + j] = C[j];
 	});
 	std::vector<int> box_first(n + 1, 0);
-	for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + (int)cand[i].size();
+	for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + ccount[i];
 	const int nb = box_first[n];
 	std::vector<MapBox> boxes(nb);
 	std::vector<int64_t> qoff(nb + 1, 0), toff(nb + 1, 0), coff(nb + 1, 0);
 	std::vector<int32_t> bw(nb), ex(nb);
 	bool bad_box = false;
 	for (int i = 0; i < n; ++i)
-		for (size_t j = 0; j < cand[i].size(); ++j) {
-			const GdCand &c = cand[i][j];
+		for (int j = 0; j < ccount[i]; ++j) {
+			const GdCand &c = cflat[(size_t)cfirst[i] + j];
 			const int b = box_first[i] + (int)j;
 			const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
 			MapBox &M = boxes[b];
@@ -562,15 +607,19 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	if (dp_lock.owns_lock()) dp_lock.unlock();
 	ctx->stage_s[3] += gd_now() - t0, t0 = gd_now();
 	// ---- P1-P3 (host threads) ---------------------------------------------------------------------------------------------
+	static std::atomic<uint64_t> call_counter{0};
+	const uint64_t call_id = ++call_counter; // names the slabs of this call (GdRegSlab)
+	std::atomic<int> no_mem{0};
 	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
 		n_regs[i] = 0, regs[i] = nullptr;
-		const size_t nc = cand[i].size();
+		const size_t nc = (size_t)ccount[i];
 		if (!nc) return;
+		std::vector<GdCand> C(cflat.begin() + cfirst[i], cflat.begin() + cfirst[i] + ccount[i]); // the records grow CIGARs: this thread's copy
 		const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
 		const uint8_t *enc = B.enc + B.roff[i];
 		std::vector<uint8_t> rev;
 		bool need_rev = false;
-		for (auto &c : cand[i]) need_rev |= c.v.str != 0;
+		for (auto &c : C) need_rev |= c.v.str != 0;
 		if (need_rev) { rev.resize(rl); for (uint32_t j = 0; j < rl; ++j) rev[rl - 1 - j] = enc[j] ^ 3; }
 		std::vector<GdDpResult> dp(nc);
 		for (size_t j = 0; j < nc; ++j) {
@@ -578,10 +627,15 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig.data() + poff[b];
 		}
 		std::vector<GdReg> out;
-		if (is_sr) gd_sr_finish(cand[i], dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
-		else gd_lr_finish(cand[i], dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
-		gd_regs_out(out, &n_regs[i], &regs[i]);
+		if (is_sr) gd_sr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
+		else gd_lr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
+		if (out.empty()) return;
+		bool head = false;
+		void *at = gd_reg_slab_take(call_id, gd_regs_bytes(out), head);
+		if (!at) { no_mem.store(1); return; }
+		gd_regs_fill(out, at, head, &n_regs[i], &regs[i]);
 	});
+	if (no_mem.load()) { gdiet_hip_free_regs(n, n_regs, regs); ctx->err = "out of host memory for the records"; return GDIET_E_NOMEM; }
 	ctx->stage_s[4] += gd_now() - t0;
 	return GDIET_OK;
 }

@@ -193,12 +193,13 @@ typedef struct {
 	uint32_t mapq, rev, sam_pri;
 	int32_t dp_score, dp_max;
 	uint32_t n_ambi, n_cigar;
-	uint32_t *cigar;              /* points into the allocation of the record array it belongs to */
+	uint32_t *cigar;              /* points into the allocation the record belongs to */
 } gdiet_reg_t;
 
 /* Map n_reads single-segment reads (ASCII sequences).  On return regs[i] is a malloc'd array of n_regs[i] records
- * (NULL when n_regs[i] == 0, as LR/map.c:1915), in the order mm_map_frag leaves them; the records' CIGARs live in the same
- * allocation.  Free with gdiet_hip_free_regs only. */
+ * (NULL when n_regs[i] == 0, as LR/map.c:1915), in the order mm_map_frag leaves them.  The records and CIGARs of a batch share
+ * a few large allocations: release them with ONE gdiet_hip_free_regs call on the same n_reads / n_regs / regs arrays, never with
+ * free() on a single regs[i]. */
 int gdiet_hip_map_batch(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, int n_reads,
                         const char *const *seqs, const int32_t *lens, int32_t *n_regs, gdiet_reg_t **regs);
 void gdiet_hip_free_regs(int n_reads, int32_t *n_regs, gdiet_reg_t **regs);

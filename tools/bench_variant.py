@@ -71,16 +71,22 @@ def main():
         m.set_inflight(a.inflight)
         for t in [m.submit(batch) for _ in range(a.inflight)]:  # every lane allocates its scratch once
             res = m.wait(t)
-    st, open_t, t0 = [], [], time.perf_counter()
+    st, open_t, main_t, t0 = [], [], [], time.perf_counter()
     for _ in range(a.steps):
         if a.inflight == 1:
             res = m.map_uploaded(batch)
             st.append(m.stage_seconds())
         else:
+            ta = time.perf_counter()
             open_t.append(m.submit(batch))
+            tb = time.perf_counter()
             if len(open_t) == a.inflight:
+                res = None  # (frees the previous step's records)
+                tc = time.perf_counter()
                 res = m.wait(open_t.pop(0))
+                td = time.perf_counter()
                 st.append(m.stage_seconds())
+                main_t.append((tb - ta, tc - tb, td - tc))
     while open_t:
         res = m.wait(open_t.pop(0))
         st.append(m.stage_seconds())
@@ -93,6 +99,7 @@ def main():
                       "mapped_Mbases_per_s": mapped / dt / 1e6, "reads_per_s": n / dt, "index_build_s": round(t_idx, 1), "ref_mbp": a.ref_mbp,
                       "stage_ms": {"seed": 1e3 * s[0], "vote": 1e3 * s[1], "host_geometry": 1e3 * s[2], "gather_dp_backtrack": 1e3 * s[3],
                                    "host_post": 1e3 * s[4], "other": 1e3 * s[5]},
+                      "caller_ms": dict(zip(("submit", "free_previous", "wait"), (1e3 * np.mean(np.array(main_t), axis=0)).round(2).tolist())) if main_t else None,
                       "dp_kernel_ms": dp, "backtrack_ms": bt, "dp_gcups": cells / dp / 1e6 if dp else None, "kernel_mask": ctx.last_kernel_mask()}))
 
 
