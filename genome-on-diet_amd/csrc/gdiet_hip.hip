@@ -12,6 +12,7 @@
 #include <functional>
 #include <atomic>
 #include <deque>
+#include <unordered_map>
 #include <memory>
 #include <sched.h>
 
@@ -47,10 +48,12 @@ struct gdiet_ctx {
 	int index_on_device = 1;           // GDIET_INDEX_BUILD=host: gdiet_hip_index_build sketches and sorts on host threads instead
 	int fuse_bt = 1;                   // GDIET_FUSE_BT=0: the 64-lane kernel leaves the backtrack to the separate kernel
 	bool single_affine = false;        // set for the duration of a gdiet_hip_ksw_extz2_batch call: single-affine kernel variants
-	std::vector<KswTask> h_tasks;
 	std::vector<int32_t> h_ids;
 	// per-read mapping path (map_pipeline.hip.h)
 	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack;
+	std::vector<uint8_t> h_vo;  // host copy of the vote records' heads, kept between batches
+	DevBuf h_boxes, h_cand, h_tasks, h_seedout, h_res, h_cig; // HOST buffers kept between batches (gd_host_grow): the per-batch tables of a
+	                                                           // short-read batch are tens of MB each, and allocated fresh they cost page faults
 	int host_threads = 8;
 	int lane_threads = 8;              // host threads this lane may use inside gd_map_range
 	void *pool = nullptr;              // GdPool (map_pipeline.hip.h), created on first use
@@ -216,6 +219,8 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack};
 	for (DevBuf *b : bufs)
 		if (b->p) (void)hipFree(b->p);
+	DevBuf *hosts[] = {&ctx->h_boxes, &ctx->h_cand, &ctx->h_tasks, &ctx->h_seedout, &ctx->h_res, &ctx->h_cig};
+	for (DevBuf *b : hosts) free(b->p);
 	for (int i = 0; i < 4; ++i)
 		if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
 	for (int i = 0; i < 3; ++i)
@@ -326,6 +331,21 @@ static int gd_consts(gdiet_ctx *ctx, const gdiet_ksw_score_t *sc, KswConst &K)
 	return GDIET_OK;
 }
 
+// host buffer that only grows and is kept between batches (contents are not preserved).  Plain pageable memory: pinning these
+// was measured -- neutral for short reads, and 2-3 % slower for HiFi batches (the asynchronous device-to-host copy of the DP
+// results then waits behind the other batches' kernels instead of being staged at once).
+static int gd_host_grow(gdiet_ctx *ctx, DevBuf &b, size_t bytes)
+{
+	if (bytes <= b.cap) return GDIET_OK;
+	free(b.p);
+	b.p = nullptr, b.cap = 0;
+	const size_t want = bytes + (bytes >> 2) + 4096;
+	b.p = malloc(want);
+	if (!b.p) { ctx->err = "out of host memory (" + std::to_string(want) + " bytes)"; return GDIET_E_NOMEM; }
+	b.cap = want;
+	return GDIET_OK;
+}
+
 // ---- device-pointer entry point ----------------------------------------------------------------------------
 
 // The work of gdiet_hip_ksw_extd2_batch_dev.  h_cigar_off / h_exact_score: host copies of the two small device arrays the
@@ -364,7 +384,8 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	const int64_t *h_cig = h_cigar_off;
 	const int32_t *h_ex = h_exact_score;
 
-	ctx->h_tasks.resize(n);
+	if ((rc = gd_host_grow(ctx, ctx->h_tasks, sizeof(KswTask) * (size_t)n))) return rc;
+	KswTask *h_tasks = (KswTask *)ctx->h_tasks.p;
 	const bool wave_scoring_ok = gd_wave_scoring_ok(K);
 	size_t bt = 0;
 	uint64_t cells_sum = 0, alg_sum = 0;
@@ -373,7 +394,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	ctx->last_mask = 0;
 	struct { int qlen = -1, tlen = -1, w = 0; int32_t kind = 0, row_bytes = 0; } memo;
 	for (int i = 0; i < n; ++i) {
-		KswTask &T = ctx->h_tasks[i];
+		KswTask &T = h_tasks[i];
 		T.qoff = h_qoff[i], T.toff = h_toff[i];
 		T.qlen = (int)(h_qoff[i + 1] - h_qoff[i]), T.tlen = (int)(h_toff[i + 1] - h_toff[i]);
 		T.w = h_w[i];
@@ -409,16 +430,35 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	for (int k = 0; k < 4; ++k) {
 		bool uniform = true;
 		for (size_t j = 1; j < ids[k].size() && uniform; ++j) {
-			const KswTask &A = ctx->h_tasks[ids[k][0]], &B = ctx->h_tasks[ids[k][j]];
+			const KswTask &A = h_tasks[ids[k][0]], &B = h_tasks[ids[k][j]];
 			uniform = A.qlen == B.qlen && A.tlen == B.tlen && A.w == B.w;
 		}
 		if (uniform) continue;
-		std::stable_sort(ids[k].begin(), ids[k].end(), [&](int a, int b) {
-			const KswTask &A = ctx->h_tasks[a], &B = ctx->h_tasks[b];
+		// (a stable sort by geometry, done by grouping: a short-read batch has 400 k alignments but a few dozen geometries)
+		struct Geo { int qlen, tlen, w; std::vector<int32_t> members; };
+		std::vector<Geo> geos;
+		std::unordered_map<uint64_t, std::vector<int>> slot_of; // hash of the geometry -> geos[] entries with that hash
+		int g_prev = -1;
+		for (int32_t id : ids[k]) {
+			const KswTask &A = h_tasks[id];
+			if (g_prev >= 0 && geos[g_prev].qlen == A.qlen && geos[g_prev].tlen == A.tlen && geos[g_prev].w == A.w) { geos[g_prev].members.push_back(id); continue; }
+			const uint64_t h = ((uint64_t)(uint32_t)A.qlen * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)A.tlen * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)(uint32_t)A.w;
+			std::vector<int> &cand = slot_of[h];
+			int g = -1;
+			for (int c : cand) if (geos[c].qlen == A.qlen && geos[c].tlen == A.tlen && geos[c].w == A.w) { g = c; break; }
+			if (g < 0) { g = (int)geos.size(); geos.push_back(Geo{A.qlen, A.tlen, A.w, {}}); cand.push_back(g); }
+			geos[g].members.push_back(id), g_prev = g;
+		}
+		std::vector<int> order(geos.size());
+		for (size_t g = 0; g < geos.size(); ++g) order[g] = (int)g;
+		std::sort(order.begin(), order.end(), [&](int a, int b) {
+			const Geo &A = geos[a], &B = geos[b];
 			if ((int64_t)A.qlen + A.tlen != (int64_t)B.qlen + B.tlen) return (int64_t)A.qlen + A.tlen > (int64_t)B.qlen + B.tlen;
-			if (A.qlen != B.qlen) return A.qlen > B.qlen; // equal geometries become neighbours (16-lane quartets below)
+			if (A.qlen != B.qlen) return A.qlen > B.qlen; // equal geometries are neighbours (16-lane quartets below)
 			return A.w > B.w;
 		});
+		size_t at = 0;
+		for (int g : order) for (int32_t id : geos[g].members) ids[k][at++] = id;
 	}
 	// the 16-lane kernel runs four alignments of identical (qlen, tlen, w) per wavefront: cut the sorted list into quartets
 	// (-1 pads an incomplete one)
@@ -427,10 +467,10 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		const std::vector<int32_t> &v = ids[GD_KIND_WAVE16];
 		size_t i = 0;
 		while (i < v.size()) {
-			const KswTask &A = ctx->h_tasks[v[i]];
+			const KswTask &A = h_tasks[v[i]];
 			size_t j = i + 1;
 			while (j < v.size() && j < i + 4) {
-				const KswTask &B = ctx->h_tasks[v[j]];
+				const KswTask &B = h_tasks[v[j]];
 				if (B.qlen != A.qlen || B.tlen != A.tlen || B.w != A.w) break;
 				++j;
 			}
@@ -464,7 +504,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * ctx->h_ids.size()))) return rc;
 	if ((rc = gd_grow(ctx, ctx->status, sizeof(int32_t) * n))) return rc;
-	GD_HIP(hipMemcpyAsync(ctx->tasks.p, ctx->h_tasks.data(), sizeof(KswTask) * n, hipMemcpyHostToDevice, stream));
+	GD_HIP(hipMemcpyAsync(ctx->tasks.p, h_tasks, sizeof(KswTask) * n, hipMemcpyHostToDevice, stream));
 	GD_HIP(hipMemcpyAsync(ctx->ids.p, ctx->h_ids.data(), sizeof(int32_t) * ctx->h_ids.size(), hipMemcpyHostToDevice, stream));
 
 	const KswTask *d_tasks = (const KswTask *)ctx->tasks.p;

@@ -77,6 +77,27 @@ struct GdCand { // vt_t of LR/map.c:1033-1045 plus the DP box
 	int32_t exact_score = GD_NEG_INF_SCORE; // != NEG_INF: try the exact-match pre-filter (LR/map.c:1748)
 };
 
+// a candidate between the box stage and the post-processing, without its (still empty) record: trivially copyable, so that the
+// candidates of a whole batch can live in one reused flat buffer
+struct GdCandBox {
+	GdVt v;
+	int next, concat, valid;
+	uint32_t target_id, target_start, target_end, query_start, query_end, qlen, tlen, qseq_off;
+	int32_t exact_score;
+};
+static inline GdCandBox gd_cand_box(const GdCand &c)
+{
+	GdCandBox b;
+	b.v = c.v, b.next = c.next, b.concat = c.concat, b.valid = c.valid, b.target_id = c.target_id, b.target_start = c.target_start, b.target_end = c.target_end;
+	b.query_start = c.query_start, b.query_end = c.query_end, b.qlen = c.qlen, b.tlen = c.tlen, b.qseq_off = c.qseq_off, b.exact_score = c.exact_score;
+	return b;
+}
+static inline void gd_cand_unbox(const GdCandBox &b, GdCand &c)
+{
+	c.v = b.v, c.next = b.next, c.concat = b.concat, c.valid = b.valid, c.target_id = b.target_id, c.target_start = b.target_start, c.target_end = b.target_end;
+	c.query_start = b.query_start, c.query_end = b.query_end, c.qlen = b.qlen, c.tlen = b.tlen, c.qseq_off = b.qseq_off, c.exact_score = b.exact_score;
+}
+
 // ---- G1 (second half): link candidates for CIGAR concatenation and derive the DP boxes, LR/map.c:1467-1590,1654-1713
 static inline void gd_lr_link_and_boxes(std::vector<GdCand> &C, const GdMapOpt &O, const GdRefView &R, uint32_t qlen_sum)
 {

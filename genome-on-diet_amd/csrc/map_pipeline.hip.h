@@ -454,7 +454,8 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	const int64_t *d_roff = (const int64_t *)B.d_roff;
 	ctx->stage_s[5] += gd_now() - t0, t0 = gd_now();
 	// ---- S1-S5 ----------------------------------------------------------------------------------------------------
-	std::vector<MapSeedOut> so(n);
+	if ((rc = gd_host_grow(ctx, ctx->h_seedout, sizeof(MapSeedOut) * (size_t)n))) return rc;
+	MapSeedOut *so = (MapSeedOut *)ctx->h_seedout.p;
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		// one read per thread (the plain sequential form) for short reads -- a 150 bp read has ~75 sparsified bases, far too few to
 		// split over 64 lanes (measured 18x faster at 150 bp) -- and on request (GDIET_SEED_KERNEL=thread) for A/B checks
@@ -464,7 +465,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
 			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), std::max<size_t>((size_t)O.w * 64 * sizeof(GdMini), MAP_SORT_CAP * sizeof(uint64_t)), s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
-		GD_HIP(hipMemcpyAsync(so.data(), ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
+		GD_HIP(hipMemcpyAsync(so, ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
 		GD_HIP(hipStreamSynchronize(s));
 		bool overflow = false;
 		for (int i = 0; i < n; ++i) overflow |= so[i].n_seeds < 0;
@@ -492,8 +493,9 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// only the head of every record can be in use: n_cand + at most AF_max_loc (ShortReads) / vt_nb_loc + 2 (LongReads) candidates;
 	// the host copy is packed to that size (a full-size array would be 680 B per read: 178 MB to allocate and clear per 262 k short reads)
 	const size_t vo_head = offsetof(MapVoteOut, cand) + sizeof(GdVt) * std::min<size_t>(is_sr ? (size_t)O.af_max_loc : (size_t)O.vt_nb_loc + 2, GDM_MAX_VT);
-	std::unique_ptr<uint8_t[]> vo_raw(new uint8_t[vo_head * (size_t)n]);
-	GD_HIP(hipMemcpy2DAsync(vo_raw.get(), vo_head, ctx->m_voteout.p, sizeof(MapVoteOut), vo_head, (size_t)n, hipMemcpyDeviceToHost, s));
+	if (ctx->h_vo.size() < vo_head * (size_t)n) ctx->h_vo.resize(vo_head * (size_t)n + (vo_head * (size_t)n >> 2));
+	const uint8_t *vo_raw = ctx->h_vo.data();
+	GD_HIP(hipMemcpy2DAsync(ctx->h_vo.data(), vo_head, ctx->m_voteout.p, sizeof(MapVoteOut), vo_head, (size_t)n, hipMemcpyDeviceToHost, s));
 	GD_HIP(hipStreamSynchronize(s));
 	ctx->stage_s[1] += gd_now() - t0, t0 = gd_now();
 	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
@@ -502,10 +504,11 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// vectors would be allocated by the workers and released by this thread -- a quarter of a million cross-thread frees per
 	// short-read batch, each contending for another thread's malloc arena.
 	std::vector<int> cfirst(n + 1, 0), ccount(n, 0);
-	for (int i = 0; i < n; ++i) cfirst[i + 1] = cfirst[i] + (int)reinterpret_cast<const MapVoteOut *>(vo_raw.get() + vo_head * (size_t)i)->n_cand;
-	std::vector<GdCand> cflat((size_t)cfirst[n]);
+	for (int i = 0; i < n; ++i) cfirst[i + 1] = cfirst[i] + (int)reinterpret_cast<const MapVoteOut *>(vo_raw + vo_head * (size_t)i)->n_cand;
+	if ((rc = gd_host_grow(ctx, ctx->h_cand, sizeof(GdCandBox) * (size_t)cfirst[n]))) return rc;
+	GdCandBox *cflat = (GdCandBox *)ctx->h_cand.p; // entries [cfirst[i], cfirst[i] + ccount[i]) are written below, nothing else is read
 	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
-		const MapVoteOut &vo_i = *reinterpret_cast<const MapVoteOut *>(vo_raw.get() + vo_head * (size_t)i); // head of the record only
+		const MapVoteOut &vo_i = *reinterpret_cast<const MapVoteOut *>(vo_raw + vo_head * (size_t)i); // head of the record only
 		const unsigned nc = vo_i.n_cand;
 		if (!nc) return;
 		std::vector<GdCand> C(nc);
@@ -513,20 +516,29 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		if (is_sr) gd_sr_boxes(C, O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
 		else gd_lr_link_and_boxes(C, O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
 		ccount[i] = (int)std::min<size_t>(C.size(), nc);
-		for (int j = 0; j < ccount[i]; ++j) cflat[(size_t)cfirst[i] + j] = C[j];
+		for (int j = 0; j < ccount[i]; ++j) cflat[(size_t)cfirst[i] + j] = gd_cand_box(C[j]);
 	});
 	std::vector<int> box_first(n + 1, 0);
 	for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + ccount[i];
 	const int nb = box_first[n];
-	std::vector<MapBox> boxes(nb);
+	if ((rc = gd_host_grow(ctx, ctx->h_boxes, sizeof(MapBox) * (size_t)std::max(nb, 1)))) return rc;
+	MapBox *boxes = (MapBox *)ctx->h_boxes.p;
 	std::vector<int64_t> qoff(nb + 1, 0), toff(nb + 1, 0), coff(nb + 1, 0);
 	std::vector<int32_t> bw(nb), ex(nb);
-	bool bad_box = false;
+	// window offsets: a running sum over the boxes in batch order; the boxes themselves are filled by the host threads
 	for (int i = 0; i < n; ++i)
 		for (int j = 0; j < ccount[i]; ++j) {
-			const GdCand &c = cflat[(size_t)cfirst[i] + j];
-			const int b = box_first[i] + (int)j;
-			const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
+			const GdCandBox &c = cflat[(size_t)cfirst[i] + j];
+			const int b = box_first[i] + j;
+			qoff[b + 1] = qoff[b] + c.qlen, toff[b + 1] = toff[b] + c.tlen;
+			coff[b + 1] = coff[b] + c.qlen + c.tlen;
+		}
+	std::atomic<int> bad_any{0};
+	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
+		const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
+		for (int j = 0; j < ccount[i]; ++j) {
+			const GdCandBox &c = cflat[(size_t)cfirst[i] + j];
+			const int b = box_first[i] + j;
 			MapBox &M = boxes[b];
 			M.read_off = B.roff[i], M.read_len = rl, M.qseq_off = c.qseq_off, M.qlen = c.qlen, M.tlen = c.tlen, M.rev = c.v.str;
 			// a window hanging off a contig (or a wrapped coordinate) reads stale memory in the reference; here the part that
@@ -538,16 +550,17 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 				src = R.seq[c.target_id].offset + c.target_start;
 			}
 			M.t_avail = avail, M.t_src = src;
-			if (c.qlen == 0 || c.tlen == 0 || c.qlen > rl || c.qseq_off + c.qlen > rl || c.tlen > 8u * rl + 100000u) bad_box = true;
+			if (c.qlen == 0 || c.tlen == 0 || c.qlen > rl || c.qseq_off + c.qlen > rl || c.tlen > 8u * rl + 100000u) bad_any.store(1);
 			M.q_dst = qoff[b], M.t_dst = toff[b];
-			qoff[b + 1] = qoff[b] + c.qlen, toff[b + 1] = toff[b] + c.tlen;
-			coff[b + 1] = coff[b] + c.qlen + c.tlen;
 			bw[b] = is_sr ? (int32_t)gd_sr_bw((int)rl, D.sr) : (int32_t)O.bw, ex[b] = c.exact_score; // SR/map.c:624-631,925 ; LR/map.c:1800
 		}
+	});
+	const bool bad_box = bad_any.load() != 0;
 	if (bad_box) { ctx->err = "degenerate DP box (candidate window outside the read/contig); the reference's behaviour is undefined there"; return GDIET_E_PARAM; }
 	ctx->stage_s[2] += gd_now() - t0, t0 = gd_now();
-	std::vector<int32_t> h_score(nb), h_ncig(nb);
-	std::vector<uint32_t> h_cig;
+	if ((rc = gd_host_grow(ctx, ctx->h_res, sizeof(int32_t) * 2 * (size_t)std::max(nb, 1)))) return rc;
+	int32_t *h_score = (int32_t *)ctx->h_res.p, *h_ncig = h_score + nb;
+	uint32_t *h_cig = nullptr;
 	std::vector<int64_t> poff(1, 0);
 	// an async lane shares its parent's backtrace arena (two whole-batch arenas do not fit in HBM, and concurrent DP kernels of
 	// smaller batches measured slower): the DP stages take turns
@@ -560,7 +573,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		if ((rc = gd_grow(ctx, ctx->m_cig, sizeof(uint32_t) * ((size_t)coff[nb] + 1)))) return rc;
 		int64_t *d_coff = (int64_t *)ctx->m_aux.p;
 		int32_t *d_ex = (int32_t *)(d_coff + nb + 1), *d_score = d_ex + nb, *d_ncig = d_score + nb;
-		GD_HIP(hipMemcpyAsync(ctx->m_boxes.p, boxes.data(), sizeof(MapBox) * nb, hipMemcpyHostToDevice, s));
+		GD_HIP(hipMemcpyAsync(ctx->m_boxes.p, boxes, sizeof(MapBox) * nb, hipMemcpyHostToDevice, s));
 		GD_HIP(hipMemcpyAsync(d_coff, coff.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, s));
 		GD_HIP(hipMemcpyAsync(d_ex, ex.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
 		hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(64), 0, s, nb, (const MapBox *)ctx->m_boxes.p, d_reads, (const uint32_t *)ix->d_S,
@@ -586,21 +599,22 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			if (!ctx->own_arena) GD_HIP(hipEventRecord(ctx->parent->arena_ev, sd)); // the backtrack is done by then: the CIGARs sit in this lane's own buffer
 			if (dp_lock.owns_lock()) dp_lock.unlock();
 		}
-		GD_HIP(hipMemcpyAsync(h_score.data(), d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
-		GD_HIP(hipMemcpyAsync(h_ncig.data(), d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
+		GD_HIP(hipMemcpyAsync(h_score, d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
+		GD_HIP(hipMemcpyAsync(h_ncig, d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipStreamSynchronize(sd));
 		// CIGARs are short compared with their capacity (qlen+tlen): pack them on the device, then one copy
 		for (int b = 0; b < nb; ++b) if (h_ncig[b] > coff[b + 1] - coff[b]) { ctx->err = "CIGAR capacity exceeded"; return GDIET_E_CIGAR_CAP; }
 		poff.assign(nb + 1, 0);
 		for (int b = 0; b < nb; ++b) poff[b + 1] = poff[b] + std::max(h_ncig[b], 0);
-		h_cig.resize((size_t)poff[nb] + 1);
+		if ((rc = gd_host_grow(ctx, ctx->h_cig, sizeof(uint32_t) * ((size_t)poff[nb] + 1)))) return rc;
+		h_cig = (uint32_t *)ctx->h_cig.p;
 		if (poff[nb] > 0) {
 			if ((rc = gd_grow(ctx, ctx->m_pack, sizeof(uint32_t) * (size_t)poff[nb] + sizeof(int64_t) * (nb + 1) + 64))) return rc;
 			int64_t *d_poff = (int64_t *)ctx->m_pack.p;
 			uint32_t *d_packed = (uint32_t *)(d_poff + nb + 1);
 			GD_HIP(hipMemcpyAsync(d_poff, poff.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, s));
 			hipLaunchKernelGGL(map_pack_cigar_kernel, dim3(nb), dim3(64), 0, s, nb, (const uint32_t *)ctx->m_cig.p, (const int64_t *)d_coff, (const int64_t *)d_poff, d_packed);
-			GD_HIP(hipMemcpyAsync(h_cig.data(), d_packed, sizeof(uint32_t) * (size_t)poff[nb], hipMemcpyDeviceToHost, s));
+			GD_HIP(hipMemcpyAsync(h_cig, d_packed, sizeof(uint32_t) * (size_t)poff[nb], hipMemcpyDeviceToHost, s));
 			GD_HIP(hipStreamSynchronize(s));
 		}
 	}
@@ -614,7 +628,8 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		n_regs[i] = 0, regs[i] = nullptr;
 		const size_t nc = (size_t)ccount[i];
 		if (!nc) return;
-		std::vector<GdCand> C(cflat.begin() + cfirst[i], cflat.begin() + cfirst[i] + ccount[i]); // the records grow CIGARs: this thread's copy
+		std::vector<GdCand> C(nc); // the records grow CIGARs: this thread's copy
+		for (size_t j = 0; j < nc; ++j) gd_cand_unbox(cflat[(size_t)cfirst[i] + j], C[j]);
 		const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
 		const uint8_t *enc = B.enc + B.roff[i];
 		std::vector<uint8_t> rev;
@@ -624,7 +639,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		std::vector<GdDpResult> dp(nc);
 		for (size_t j = 0; j < nc; ++j) {
 			const int b = box_first[i] + (int)j;
-			dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig.data() + poff[b];
+			dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig + poff[b];
 		}
 		std::vector<GdReg> out;
 		if (is_sr) gd_sr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
