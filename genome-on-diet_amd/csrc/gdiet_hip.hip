@@ -280,6 +280,8 @@ static int gd_generic_cap(int qlen, int tlen, int w)
 
 static inline size_t gd_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+static const int gd_group_lanes = getenv("GDIET_GROUP_LANES") ? atoi(getenv("GDIET_GROUP_LANES")) : 0; // 16: always four alignments per wavefront
+
 // decide kernel + backtrace geometry of one alignment
 static void gd_plan_one(int mode, bool wave_scoring_ok, int qlen, int tlen, int w, int32_t &kind, int32_t &row_bytes)
 {
@@ -287,7 +289,14 @@ static void gd_plan_one(int mode, bool wave_scoring_ok, int qlen, int tlen, int 
 	kind = GD_KIND_GENERIC, row_bytes = ncol * 16;
 	if (mode == 1 || !wave_scoring_ok) return;
 	if (gd_wave_supported(qlen, tlen, w, 64)) {
-		if (gd_wave_supported(qlen, tlen, w, 16)) kind = GD_KIND_WAVE16, row_bytes = 16 * 16;
+		if (gd_wave_supported(qlen, tlen, w, 16)) {
+			// short alignments: several per wavefront.  Targets of <= 128 / 160 bases keep every block in a lane of its own: groups of
+			// 8 / 10 lanes (8 / 6 alignments per wavefront) instead of one DPP row of 16 each
+			// (the reference's n_col_ counts one block more -- the spill of the score row above the window -- but beyond the target's
+			// last block that spill is never read)
+			const int g = gd_group_lanes == 16 ? 16 : tlen <= 128 ? 8 : tlen <= 160 ? 10 : 16;
+			kind = GD_KIND_WAVE16, row_bytes = g * 16;
+		}
 		else kind = GD_KIND_WAVE64, row_bytes = 64 * 16;
 	} else if (gd_wave_supported(qlen, tlen, w, 128)) kind = GD_KIND_WAVE128; // row_bytes stays n_col_*16
 }
@@ -460,30 +469,32 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		size_t at = 0;
 		for (int g : order) for (int32_t id : geos[g].members) ids[k][at++] = id;
 	}
-	// the 16-lane kernel runs four alignments of identical (qlen, tlen, w) per wavefront: cut the sorted list into quartets
-	// (-1 pads an incomplete one)
-	std::vector<int32_t> quartets;
+	// the short-alignment kernels run 4 / 6 / 8 alignments of identical (qlen, tlen, w) per wavefront (groups of 16 / 10 / 8 lanes):
+	// cut the sorted list into such groups, one list per group width (-1 pads an incomplete group)
+	std::vector<int32_t> groups[3]; // [0]: 16 lanes, [1]: 10, [2]: 8
 	{
 		const std::vector<int32_t> &v = ids[GD_KIND_WAVE16];
 		size_t i = 0;
 		while (i < v.size()) {
 			const KswTask &A = h_tasks[v[i]];
+			const int gl = A.row_bytes >> 4, per = 64 / gl, which = gl == 16 ? 0 : gl == 10 ? 1 : 2;
 			size_t j = i + 1;
-			while (j < v.size() && j < i + 4) {
+			while (j < v.size() && j < i + per) {
 				const KswTask &B = h_tasks[v[j]];
 				if (B.qlen != A.qlen || B.tlen != A.tlen || B.w != A.w) break;
 				++j;
 			}
-			for (size_t k = i; k < i + 4; ++k) quartets.push_back(k < j ? v[k] : -1);
+			for (size_t k = i; k < i + per; ++k) groups[which].push_back(k < j ? v[k] : -1);
 			i = j;
 		}
 	}
 	ctx->h_ids.clear();
-	size_t id_off[4];
+	size_t id_off[4], group_off[3] = {0, 0, 0};
 	for (int k = 0; k < 4; ++k) {
 		id_off[k] = ctx->h_ids.size();
-		if (k == GD_KIND_WAVE16) ctx->h_ids.insert(ctx->h_ids.end(), quartets.begin(), quartets.end());
-		else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
+		if (k == GD_KIND_WAVE16) {
+			for (int g = 0; g < 3; ++g) group_off[g] = ctx->h_ids.size(), ctx->h_ids.insert(ctx->h_ids.end(), groups[g].begin(), groups[g].end());
+		} else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
 	}
 	ctx->last_cells = cells_sum, ctx->last_alg_bytes = alg_sum;
 	// An async lane works in its parent's arena, taking turns behind parent->arena_ev -- unless the batch's backtrace is small
@@ -546,9 +557,11 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		backtrack(d_ids + id_off[GD_KIND_WAVE64] + n_head, n64 - n_head, ctx->stream2);
 		GD_HIP(hipEventRecord(ctx->ev2[2], ctx->stream2));
 	}
-	if (!ids[GD_KIND_WAVE16].empty())
-		gd_launch_wave16(d_tasks, d_ids + id_off[GD_KIND_WAVE16], (int)(quartets.size() / 4), d_qseq, d_tseq, d_bt,
-		                 d_status, d_score, K, stream, single);
+	if (!ids[GD_KIND_WAVE16].empty()) {
+		gd_launch_wave_groups<16>(d_tasks, d_ids + group_off[0], (int)(groups[0].size() / 4), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
+		gd_launch_wave_groups<10>(d_tasks, d_ids + group_off[1], (int)(groups[1].size() / 6), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
+		gd_launch_wave_groups<8>(d_tasks, d_ids + group_off[2], (int)(groups[2].size() / 8), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
+	}
 	if (!ids[GD_KIND_WAVE128].empty()) {
 		// few wide-band alignments (the arena bounds how many 50 kbp ONT alignments fit): two wavefronts share one, halving the
 		// serial chain; plenty of them: one wavefront each, two blocks per lane, no barrier

@@ -17,8 +17,9 @@ __device__ __forceinline__ size_t gd_bt_index(const KswTask &T, int r, int i, in
 	const int lanes = T.row_bytes >> 4;
 	const int c = i & 15;
 	const int g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
-	// 16/64-lane kernels: ring of `lanes` blocks; two-blocks-per-lane kernel: the reference's window-relative block position
-	const int bpos = T.kind == GD_KIND_WAVE128 ? (i >> 4) - (off >> 4) : ((i >> 4) & (lanes - 1));
+	// 16/64-lane kernels: ring of `lanes` blocks (the 10- and 8-lane groups of the short-read kernel hold every block of their
+	// alignment at once: no ring); two-blocks-per-lane kernel: the reference's window-relative block position
+	const int bpos = T.kind == GD_KIND_WAVE128 ? (i >> 4) - (off >> 4) : (lanes & (lanes - 1)) ? (i >> 4) : ((i >> 4) & (lanes - 1));
 	return (size_t)r * T.row_bytes + (size_t)(bpos << 4) + (g << 2) + h;
 }
 

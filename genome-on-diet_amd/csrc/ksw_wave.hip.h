@@ -16,7 +16,9 @@
 template <int LANES> __device__ __forceinline__ u32 gdw_ror1(u32 v)
 {
 	// every lane has a source lane under a rotate, so no "old" value is needed: bound_ctrl form, no register to pre-clear
-	if (LANES == 64) return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x13C, 0xF, 0xF, true);
+	// (groups of 10 or 8 lanes hold all blocks of their alignment, block b in lane b of the group: lane b-1 is simply the previous
+	// lane of the wavefront, and block 0 never looks at what it receives)
+	if (LANES != 16) return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x13C, 0xF, 0xF, true);
 	return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, true);
 }
 
@@ -58,6 +60,10 @@ static inline bool gd_wave_supported(int qlen, int tlen, int w, int lanes)
 //              (task_ids[4*slot + row]; -1 = empty row, which shadows row 0 without storing).  Identical geometry keeps every
 //              band / boundary quantity of the row loop wave-uniform (SGPRs), exactly as in the 64-lane form; only the
 //              sequence and backtrace pointers differ between the rows.  Short reads (150 x 150) all share one geometry.
+// LANES == 10 / 8: six / eight alignments of identical geometry per wavefront, for targets of at most 160 / 128 bases: every
+//              16-cell block of such an alignment has a lane of its own for the whole run, so a group needs no ring and can be any
+//              run of consecutive lanes.  A 150 x 150 alignment uses 10 of the 16 lanes of a DPP row; six groups of ten fill 60 of
+//              the 64 lanes (lanes 60-63 shadow group 0 without storing).
 // TAG only names the launch (0: a whole batch; 1 / 2: the head / tail launch of a split batch, see gdiet_hip.hip) so that a
 // profile lists them apart.
 // DUAL = false is the single-affine (ksw_extz2) form of the same kernel: see gdw_compute.
@@ -70,7 +76,10 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
                                                              int32_t *__restrict__ score_out, WaveK K,
                                                              int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
 {
-	const int lane = threadIdx.x & 63, sub = lane & (LANES - 1), row = LANES == 64 ? 0 : lane >> 4;
+	constexpr int NG = 64 / LANES; // alignments per wavefront
+	const int lane = threadIdx.x & 63;
+	const bool spare = lane >= NG * LANES; // (10-lane groups only: lanes 60-63)
+	const int sub = spare ? lane - NG * LANES : lane % LANES, row = spare ? 0 : lane / LANES;
 	const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
 	if (slot >= n_slots) return;
 	int tid, live = 1;
@@ -78,9 +87,9 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 		tid = __builtin_amdgcn_readfirstlane(task_ids[slot]);
 		if (__builtin_amdgcn_readfirstlane(status[tid]) != GD_ST_PENDING) return;
 	} else {
-		tid = task_ids[4 * slot + row];
+		tid = task_ids[NG * slot + row];
 		const int tid0 = __builtin_amdgcn_readfirstlane(tid);
-		if (tid < 0) tid = tid0, live = 0;
+		if (tid < 0 || spare) tid = tid0, live = 0;
 		else if (status[tid] != GD_ST_PENDING) live = 0; // the exact-match pre-filter answered this one
 		if (!__builtin_amdgcn_ballot_w64(live)) return;
 	}
@@ -92,8 +101,9 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 	uint8_t *p = bt + Tp->bt_off + (size_t)sub * 16;
 	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
 	// wave-uniform copies of the query pointers for the scalar seam load
-	const uint8_t *q0 = gdw_uniform_ptr(query, 0), *q1 = q0, *q2 = q0, *q3 = q0;
-	if (LANES == 16) q1 = gdw_uniform_ptr(query, 16), q2 = gdw_uniform_ptr(query, 32), q3 = gdw_uniform_ptr(query, 48);
+	const uint8_t *qg[NG];
+#pragma unroll
+	for (int g = 0; g < NG; ++g) qg[g] = gdw_uniform_ptr(query, g * LANES);
 
 	WaveLane L;
 	gdw_load_block(L, K, sub, 0, query, qlen, target, tlen);
@@ -115,10 +125,11 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 		// (2) query window advance; the lane whose block fell below the window takes over block +LANES
 		if (r > 0) {
 			const int j = r - (prev_st_ << 4);
-			u32 seam = gdw_seam_byte(q0, qlen, j);
-			if (LANES == 16) {
-				const u32 s1 = gdw_seam_byte(q1, qlen, j), s2 = gdw_seam_byte(q2, qlen, j), s3 = gdw_seam_byte(q3, qlen, j);
-				seam = row == 0 ? seam : row == 1 ? s1 : row == 2 ? s2 : s3;
+			u32 seam = gdw_seam_byte(qg[0], qlen, j);
+#pragma unroll
+			for (int g = 1; g < NG; ++g) {
+				const u32 sg = gdw_seam_byte(qg[g], qlen, j);
+				seam = row == g ? sg : seam;
 			}
 			gdw_shift_query(L, pQ, L.blk == prev_st_, seam);
 		}
@@ -186,14 +197,15 @@ static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, in
 	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 }
-// ids: 4 task ids per wavefront (identical geometry; -1 pads an incomplete quartet), n_quartets wavefronts
-static inline void gd_launch_wave16(const KswTask *tasks, const int32_t *ids, int n_quartets, const uint8_t *q, const uint8_t *t,
-                                    uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, bool single = false)
+// ids: 64 / G task ids per wavefront (identical geometry; -1 pads an incomplete group), n_groups wavefronts; G = 16, 10 or 8
+template <int G> static inline void gd_launch_wave_groups(const KswTask *tasks, const int32_t *ids, int n_groups, const uint8_t *q, const uint8_t *t,
+                                                          uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, bool single = false)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0, false>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K, (int32_t *)nullptr, (uint32_t *)nullptr);
-	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<16, 0>), dim3((n_quartets + 3) / 4), dim3(256), 0, s, tasks, ids, n_quartets, q, t, bt, status, score, K, (int32_t *)nullptr, (uint32_t *)nullptr);
+	if (n_groups <= 0) return;
+	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<G, 0, false>), dim3((n_groups + 3) / 4), dim3(256), 0, s, tasks, ids, n_groups, q, t, bt, status, score, K, (int32_t *)nullptr, (uint32_t *)nullptr);
+	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<G, 0>), dim3((n_groups + 3) / 4), dim3(256), 0, s, tasks, ids, n_groups, q, t, bt, status, score, K, (int32_t *)nullptr, (uint32_t *)nullptr);
 }
 
 // ---- wide bands (ONT, w = 1300): 128 blocks in flight, TWO per lane ------------------------------------------------------

@@ -104,7 +104,8 @@ def test_band_exhaustion_reports_neg_inf(gpu_ctx, pkg):
 
 
 def test_short_read_quartets_match_oracle(gpu_ctx, pkg, oracle):
-    """the 16-lane kernel (four alignments of identical geometry per wavefront): a block of 150 x 150, w = 150 pairs (the
+    """the short-alignment kernels (several alignments of identical geometry per wavefront; 150 x 150 runs six to a wavefront in groups
+    of ten lanes): a block of 150 x 150, w = 150 pairs (the
     short-read shape: SR/map.c:925 passes len, len, bw), incomplete quartets, mixed geometries, Ns, exact-match rows inside a
     quartet -- all against the oracle"""
     gdo, lib = oracle
@@ -137,6 +138,37 @@ def test_short_read_quartets_match_oracle(gpu_ctx, pkg, oracle):
         assert sc[i] == o["score"], (i, len(qs[i]), len(ts[i]), ws[i], sc[i], o["score"])
         assert np.array_equal(cg[i], o["cigar"]), (i, len(qs[i]), len(ts[i]), ws[i])
     assert n_exact >= 30
+
+
+def test_short_read_group_widths_match_oracle(gpu_ctx, pkg, oracle):
+    """the short-alignment kernels pack 8 / 6 / 4 alignments of one geometry into a wavefront (groups of 8 / 10 / 16 lanes for
+    targets of <= 128 / <= 160 / more bases): targets on both sides of each limit, full and padded groups, narrow and full bands,
+    qlen != tlen, Ns -- against the oracle; and GDIET_GROUP_LANES-independent (the same pairs through the generic kernel)"""
+    gdo, lib = oracle
+    rng = np.random.default_rng(4242)
+    qs, ts, ws = [], [], []
+    for tlen in (33, 112, 127, 128, 129, 144, 159, 160, 161, 176):
+        for w in (24, 150):
+            base_q, base_t = gdo.make_pair(rng, tlen + 8, 0.0, 0.0, 0.0)
+            for i in range(19):  # 19 = two full groups of 8 + 3, three of 6 + 1, four of 4 + 3
+                q, t = gdo.make_pair(rng, tlen + 8, 0.03, 0.006, 0.006, n_frac=0.02 if i == 4 else 0.0)
+                t = t[:tlen] if len(t) >= tlen else np.concatenate([t, base_t[:tlen - len(t)]])
+                ql = tlen - (i % 3)  # a few query lengths per target length: several geometries per width
+                q = q[:ql] if len(q) >= ql else np.concatenate([q, base_q[:ql - len(q)]])
+                qs.append(q), ts.append(t), ws.append(w)
+    sc, cg = gpu_ctx.ksw_extd2_batch(qs, ts, ws, pkg.KswScore.from_preset("sr"))
+    assert gpu_ctx.last_kernel_mask() & 4
+    gpu_ctx.set_kernel_mode(1)
+    try:
+        sc_g, cg_g = gpu_ctx.ksw_extd2_batch(qs, ts, ws, pkg.KswScore.from_preset("sr"))
+    finally:
+        gpu_ctx.set_kernel_mode(0)
+    a, b, q_, e, q2, e2 = gdo.PRESETS["sr"]
+    mat = gdo.score_matrix(a, b)
+    for i in range(len(qs)):
+        o = gdo.oracle_extd2(lib, qs[i], ts[i], mat, q_, e, q2, e2, ws[i])
+        assert sc[i] == o["score"] == sc_g[i], (i, len(qs[i]), len(ts[i]), ws[i], sc[i], o["score"], sc_g[i])
+        assert np.array_equal(cg[i], o["cigar"]) and np.array_equal(cg_g[i], o["cigar"]), (i, len(qs[i]), len(ts[i]), ws[i])
 
 
 def test_device_pointer_entry_matches_host_entry(gpu_ctx, pkg, oracle):
