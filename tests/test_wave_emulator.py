@@ -16,14 +16,14 @@ def emul(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("seed,lanes,n", [(1, 64, 400), (2, 64, 400), (3, 16, 400), (4, 128, 60)])
+@pytest.mark.parametrize("seed,lanes,n", [(1, 64, 400), (2, 64, 400), (3, 16, 400), (4, 128, 60), (5, 10, 400), (6, 8, 400)])
 def test_wave_core_matches_oracle(emul, seed, lanes, n):
     out = subprocess.run([emul, str(seed), str(n), str(lanes)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
 
 
-@pytest.mark.parametrize("lanes", [16, 64])
+@pytest.mark.parametrize("lanes", [16, 64, 10])
 def test_single_affine_form_matches_extz2_oracle(emul, lanes):
     """K3: gdw_compute<false> (no X2 / Y2 half) against the oracle's ksw_extz2"""
     out = subprocess.run([emul, "9", "300", str(lanes), "single"], capture_output=True, text=True)
