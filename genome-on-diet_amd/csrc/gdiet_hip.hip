@@ -65,6 +65,7 @@ struct gdiet_ctx {
 	hipEvent_t arena_ev = nullptr;     // recorded after the last DP stage that was enqueued: the arena is free once it has completed
 	size_t lane_arena_cap = 0;         // a lane whose batch needs no more backtrace than this works in an arena of its own (set with the depth)
 	bool own_arena = false;            // (lane) the last DP stage did
+	bool shared_sticky = false;        // (lane) a recent batch did not fit a private arena
 	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool async_busy[4] = {false, false, false, false};
 	int async_next = 0, async_depth = 2;
@@ -500,7 +501,11 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	// An async lane works in its parent's arena, taking turns behind parent->arena_ev -- unless the batch's backtrace is small
 	// enough for every lane in flight to hold one of its own (long-read batches of few reads: their DP kernels then overlap, which
 	// fills the GPU while one batch's longest alignments are still running).
-	bool own = ctx->parent && bt <= ctx->parent->lane_arena_cap;
+	// (sticky: a lane that had to fall back to the shared arena stays there until its batches are clearly below the cap again --
+	// giving a 50 GB arena back and allocating it anew every other batch costs more than taking turns)
+	if (ctx->parent && bt > ctx->parent->lane_arena_cap) ctx->shared_sticky = true;
+	else if (ctx->parent && bt <= ctx->parent->lane_arena_cap / 4 * 3) ctx->shared_sticky = false;
+	bool own = ctx->parent && bt <= ctx->parent->lane_arena_cap && !ctx->shared_sticky;
 	if (own && bt > ctx->arena.cap) { // grown in big steps: freeing device memory stalls every lane
 		const size_t want = std::min(ctx->parent->lane_arena_cap, std::max<size_t>(bt * 2, (size_t)1 << 30));
 		if (gd_grow(ctx, ctx->arena, std::max(bt, want - (want >> 3) - 4096)) && gd_grow(ctx, ctx->arena, bt)) own = false, ctx->err.clear(); // no room: take turns in the shared one
