@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight (gdiet_hip_map_submit/_wait): 2 overlaps the seeding/voting/host stages of step i+1 with the DP kernel of step i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on a one-GPU box)")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK)")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads of the post-processing pool (default: the CPUs this container may use / ranks)")
     args = ap.parse_args()
 
@@ -198,8 +200,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    if args.device >= 0:
+        local = args.device
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -507,7 +507,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	else if (ctx->parent && bt <= ctx->parent->lane_arena_cap / 4 * 3) ctx->shared_sticky = false;
 	bool own = ctx->parent && bt <= ctx->parent->lane_arena_cap && !ctx->shared_sticky;
 	if (own && bt > ctx->arena.cap) { // grown in big steps: freeing device memory stalls every lane
-		const size_t want = std::min(ctx->parent->lane_arena_cap, std::max<size_t>(bt * 2, (size_t)1 << 30));
+		const size_t want = std::min(ctx->parent->lane_arena_cap, std::max<size_t>(bt + (bt >> 2), (size_t)1 << 30));
 		if (gd_grow(ctx, ctx->arena, std::max(bt, want - (want >> 3) - 4096)) && gd_grow(ctx, ctx->arena, bt)) own = false, ctx->err.clear(); // no room: take turns in the shared one
 	}
 	if (ctx->parent && !own && ctx->arena.p) { (void)hipFree(ctx->arena.p); ctx->arena.p = nullptr, ctx->arena.cap = 0; }
@@ -516,7 +516,17 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	DevBuf &arena = ctx->parent && !own ? ctx->parent->arena : ctx->arena;
 	if (arena_turn) arena_turn->lock(); // everything above was this batch's own planning: only the use of the arena is ordered
 	if (ctx->parent && !own && bt > arena.cap) GD_HIP(hipEventSynchronize(ctx->parent->arena_ev)); // growing it: the previous user must be done
-	if ((rc = gd_grow(ctx, arena, bt))) return rc;
+	if ((rc = gd_grow(ctx, arena, bt))) {
+		// a context working synchronously after batches were in flight: its idle lanes may still hold private arenas
+		bool freed = false;
+		if (!ctx->parent && rc == GDIET_E_NOMEM)
+			for (int i = 0; i < 4; ++i) {
+				gdiet_ctx *c = ctx->async_lane[i];
+				if (c && !ctx->async_busy[i] && c->arena.p) { (void)hipFree(c->arena.p); c->arena.p = nullptr, c->arena.cap = 0, freed = true; }
+			}
+		if (!freed || (rc = gd_grow(ctx, arena, bt))) return rc;
+		ctx->err.clear();
+	}
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * ctx->h_ids.size()))) return rc;
 	if ((rc = gd_grow(ctx, ctx->status, sizeof(int32_t) * n))) return rc;
