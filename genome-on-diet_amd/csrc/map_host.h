@@ -604,70 +604,82 @@ static inline void gd_lr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 
 // ---- G2: candidate geometry of the ShortReads variant, SR/map.c:779-839 -------------------------------------------------------
 // Turns the voted diagonals into len x len DP boxes; candidates the reference skips (:796-801) are removed, order is kept.
+// DP box of one short-read candidate (SR/map.c:780-930); false: the candidate is dropped
+static inline bool gd_sr_box_one(const GdVt &v, const GdMapOpt &O, const GdRefView &R, uint32_t qlen_sum, GdCandBox &b)
+{
+	const int str = (int)v.str;
+	const uint32_t target_id = v.chrom_id;
+	uint32_t start_offset, end_offset;
+	int32_t target_loc = v.first_target_loc;
+	if (str) target_loc -= (O.k - 1);
+	int32_t target_start = target_loc, target_end = target_loc;
+	const int32_t tlen = target_id < R.n_seq ? (int32_t)R.seq[target_id].len : 0;
+	if (qlen_sum > 300) {
+		if (v.first_query_loc == v.last_query_loc) return false;
+		start_offset = v.first_query_loc - (uint32_t)(O.k - 1);
+		end_offset = v.last_query_loc;
+		if (str) {
+			target_end = (int32_t)((uint32_t)target_end - start_offset);
+			target_start = (int32_t)((uint32_t)target_start - end_offset);
+			if (target_start < 0) {
+				end_offset += (uint32_t)target_start;
+				target_start = 0;
+			}
+		} else {
+			target_start = (int32_t)((uint32_t)target_start + start_offset);
+			target_end = (int32_t)((uint32_t)target_end + end_offset);
+			if (target_end + 1 > tlen) {
+				end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
+				target_end = tlen - 1;
+			}
+		}
+	} else {
+		if (str) {
+			if (target_end > tlen - 1) {
+				start_offset = (uint32_t)(target_end - (tlen - 1));
+				target_end = tlen - 1;
+			} else start_offset = 0;
+			if ((uint32_t)target_end < qlen_sum - start_offset - 1) { // int32 against unsigned: compared as unsigned (:816)
+				end_offset = start_offset + (uint32_t)target_end;
+				target_start = 0;
+			} else {
+				end_offset = qlen_sum - 1;
+				target_start = (int32_t)((uint32_t)target_end - (end_offset - start_offset));
+			}
+		} else {
+			if (target_start < 0) {
+				start_offset = (uint32_t)(-target_start);
+				target_start = 0;
+			} else start_offset = 0;
+			if ((uint32_t)(tlen - target_start) < qlen_sum - start_offset) { // (:831) unsigned compare as well
+				end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
+				target_end = tlen - 1;
+			} else {
+				end_offset = qlen_sum - 1;
+				target_end = (int32_t)((uint32_t)target_start + (end_offset - start_offset));
+			}
+		}
+	}
+	const uint32_t len = end_offset - start_offset + 1;
+	b.v = v, b.next = -1, b.concat = 0, b.valid = 1;
+	b.target_id = target_id, b.target_start = (uint32_t)target_start, b.target_end = (uint32_t)target_end;
+	b.query_start = start_offset, b.query_end = end_offset, b.qlen = len, b.tlen = len;
+	b.qseq_off = str ? qlen_sum - 1 - end_offset : start_offset; // qs = &qs_rev[qlen_sum-1-end_offset] / &qs_for[start_offset]
+	b.exact_score = qlen_sum < 300 ? (int32_t)(qlen_sum * (uint32_t)O.a) : GD_NEG_INF_SCORE; // :873-908
+	return true;
+}
+
 static inline void gd_sr_boxes(std::vector<GdCand> &C, const GdMapOpt &O, const GdRefView &R, uint32_t qlen_sum)
 {
 	std::vector<GdCand> out;
 	out.reserve(C.size());
-	for (GdCand c : C) {
-		const int str = (int)c.v.str;
-		const uint32_t target_id = c.v.chrom_id;
-		uint32_t start_offset, end_offset;
-		int32_t target_loc = c.v.first_target_loc;
-		if (str) target_loc -= (O.k - 1);
-		int32_t target_start = target_loc, target_end = target_loc;
-		const int32_t tlen = target_id < R.n_seq ? (int32_t)R.seq[target_id].len : 0;
-		if (qlen_sum > 300) {
-			if (c.v.first_query_loc == c.v.last_query_loc) continue;
-			start_offset = c.v.first_query_loc - (uint32_t)(O.k - 1);
-			end_offset = c.v.last_query_loc;
-			if (str) {
-				target_end = (int32_t)((uint32_t)target_end - start_offset);
-				target_start = (int32_t)((uint32_t)target_start - end_offset);
-				if (target_start < 0) {
-					end_offset += (uint32_t)target_start;
-					target_start = 0;
-				}
-			} else {
-				target_start = (int32_t)((uint32_t)target_start + start_offset);
-				target_end = (int32_t)((uint32_t)target_end + end_offset);
-				if (target_end + 1 > tlen) {
-					end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
-					target_end = tlen - 1;
-				}
-			}
-		} else {
-			if (str) {
-				if (target_end > tlen - 1) {
-					start_offset = (uint32_t)(target_end - (tlen - 1));
-					target_end = tlen - 1;
-				} else start_offset = 0;
-				if ((uint32_t)target_end < qlen_sum - start_offset - 1) { // int32 against unsigned: compared as unsigned (:816)
-					end_offset = start_offset + (uint32_t)target_end;
-					target_start = 0;
-				} else {
-					end_offset = qlen_sum - 1;
-					target_start = (int32_t)((uint32_t)target_end - (end_offset - start_offset));
-				}
-			} else {
-				if (target_start < 0) {
-					start_offset = (uint32_t)(-target_start);
-					target_start = 0;
-				} else start_offset = 0;
-				if ((uint32_t)(tlen - target_start) < qlen_sum - start_offset) { // (:831) unsigned compare as well
-					end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
-					target_end = tlen - 1;
-				} else {
-					end_offset = qlen_sum - 1;
-					target_end = (int32_t)((uint32_t)target_start + (end_offset - start_offset));
-				}
-			}
-		}
-		const uint32_t len = end_offset - start_offset + 1;
-		c.target_id = target_id, c.target_start = (uint32_t)target_start, c.target_end = (uint32_t)target_end;
-		c.query_start = start_offset, c.query_end = end_offset, c.qlen = len, c.tlen = len;
-		c.qseq_off = str ? qlen_sum - 1 - end_offset : start_offset; // qs = &qs_rev[qlen_sum-1-end_offset] / &qs_for[start_offset]
-		c.exact_score = qlen_sum < 300 ? (int32_t)(qlen_sum * (uint32_t)O.a) : GD_NEG_INF_SCORE; // :873-908
-		c.valid = 1;
+	for (const GdCand &c0 : C) {
+		GdCandBox b;
+		if (!gd_sr_box_one(c0.v, O, R, qlen_sum, b)) continue;
+		GdCand c = c0;
+		const int next = c.next, concat = c.concat; // (untouched by the box stage)
+		gd_cand_unbox(b, c);
+		c.next = next, c.concat = concat;
 		out.push_back(c);
 	}
 	C.swap(out);
@@ -681,7 +693,8 @@ static inline void gd_sr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 	const int g = O.a, bb = O.b < 0 ? O.b : -O.b;
 	int8_t mat[25];
 	for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? (int8_t)g : (int8_t)bb);
-	std::vector<uint8_t> tseq;
+	static thread_local std::vector<uint8_t> tseq; // (scratch kept per thread: this runs once per read, millions of times per second)
+	out.reserve(C.size());
 	for (size_t i = 0; i < C.size(); ++i) {
 		const GdCand &c = C[i];
 		// a band that emptied leaves score = KSW_NEG_INF and no CIGAR; dp_score < min_dp_max then drops the record (:955-958)
@@ -698,7 +711,7 @@ static inline void gd_sr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 		gd_update_extra(r, qseq, tseq.data(), mat, (int8_t)O.q, (int8_t)O.e, !(O.flag & GD_F_SR));
 		const uint32_t clip0 = r.rev ? qlen_sum - r.qe : (uint32_t)r.qs, clip1 = r.rev ? (uint32_t)r.qs : qlen_sum - r.qe;
 		if (!(clip0 < qlen_sum && clip1 < qlen_sum) || r.dp_score < O.min_dp_max) continue;
-		out.push_back(r);
+		out.push_back(std::move(r));
 		for (size_t k = out.size() - 1; k > 0; k--) { // full insertion by descending score (:965-973)
 			if (out[k].score > out[k - 1].score) std::swap(out[k], out[k - 1]);
 			else break;

@@ -339,6 +339,18 @@ struct GdBatchView {
 // the whole per-read path for one slice, on ctx's own stream and buffers (ctx is a lane: the parent context or one of its children)
 static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O, const GdBatchView &B, int32_t *n_regs, gdiet_reg_t **regs)
 {
+	// GDIET_TRACE_STAGES=1: wall time of the host-side sub-steps of this call to stderr (development aid)
+	static const bool trace = getenv("GDIET_TRACE_STAGES") != nullptr;
+	double tr_t = trace ? gd_now() : 0;
+	std::string tr_s;
+	auto mark = [&](const char *what) {
+		if (!trace) return;
+		const double now = gd_now();
+		char b[64];
+		snprintf(b, sizeof b, " %s %.2f", what, 1e3 * (now - tr_t));
+		tr_s += b, tr_t = now;
+	};
+
 	(void)hipSetDevice(ctx->device);
 	const int n = B.n;
 	for (int i = 0; i < 6; ++i) ctx->stage_s[i] = 0;
@@ -405,6 +417,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		if ((rc = layout(true))) return rc;
 	}
 	ctx->stage_s[0] += gd_now() - t0, t0 = gd_now();
+	mark("seed");
 	std::vector<int64_t> hoff(n + 1, 0);
 	for (int i = 0; i < n; ++i) {
 		hoff[i + 1] = hoff[i] + (so[i].n_seeds > 0 ? so[i].n_a : 0);
@@ -429,6 +442,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	GD_HIP(hipMemcpy2DAsync(ctx->h_vo.data(), vo_head, ctx->m_voteout.p, sizeof(MapVoteOut), vo_head, (size_t)n, hipMemcpyDeviceToHost, s));
 	GD_HIP(hipStreamSynchronize(s));
 	ctx->stage_s[1] += gd_now() - t0, t0 = gd_now();
+	mark("vote");
 	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
 	const GdRefView R = ix->h.ref();
 	// candidates of all reads in one flat array (capacity: what the vote kernel reported; the box stage may drop some).  Per-read
@@ -438,19 +452,27 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	for (int i = 0; i < n; ++i) cfirst[i + 1] = cfirst[i] + (int)reinterpret_cast<const MapVoteOut *>(vo_raw + vo_head * (size_t)i)->n_cand;
 	if ((rc = gd_host_grow(ctx, ctx->h_cand, sizeof(GdCandBox) * (size_t)cfirst[n]))) return rc;
 	GdCandBox *cflat = (GdCandBox *)ctx->h_cand.p; // entries [cfirst[i], cfirst[i] + ccount[i]) are written below, nothing else is read
+	mark("g:prefix");
 	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
 		const MapVoteOut &vo_i = *reinterpret_cast<const MapVoteOut *>(vo_raw + vo_head * (size_t)i); // head of the record only
 		const unsigned nc = vo_i.n_cand;
 		if (!nc) return;
+		if (is_sr) { // straight into the flat array: a quarter of a million reads per batch, nothing allocated per read
+			int k = 0;
+			for (unsigned j = 0; j < nc; ++j)
+				if (gd_sr_box_one(vo_i.cand[j], O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]), cflat[(size_t)cfirst[i] + k])) ++k;
+			ccount[i] = k;
+			return;
+		}
 		std::vector<GdCand> C(nc);
 		for (unsigned j = 0; j < nc; ++j) C[j].v = vo_i.cand[j];
-		if (is_sr) gd_sr_boxes(C, O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
-		else gd_lr_link_and_boxes(C, O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
+		gd_lr_link_and_boxes(C, O, R, (uint32_t)(B.roff[i + 1] - B.roff[i]));
 		ccount[i] = (int)std::min<size_t>(C.size(), nc);
 		for (int j = 0; j < ccount[i]; ++j) cflat[(size_t)cfirst[i] + j] = gd_cand_box(C[j]);
 	});
 	std::vector<int> box_first(n + 1, 0);
 	for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + ccount[i];
+	mark("g:boxes");
 	const int nb = box_first[n];
 	if ((rc = gd_host_grow(ctx, ctx->h_boxes, sizeof(MapBox) * (size_t)std::max(nb, 1)))) return rc;
 	MapBox *boxes = (MapBox *)ctx->h_boxes.p;
@@ -465,6 +487,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			coff[b + 1] = coff[b] + c.qlen + c.tlen;
 		}
 	std::atomic<int> bad_any{0};
+	mark("g:offsets");
 	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
 		const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
 		for (int j = 0; j < ccount[i]; ++j) {
@@ -489,6 +512,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	const bool bad_box = bad_any.load() != 0;
 	if (bad_box) { ctx->err = "degenerate DP box (candidate window outside the read/contig); the reference's behaviour is undefined there"; return GDIET_E_PARAM; }
 	ctx->stage_s[2] += gd_now() - t0, t0 = gd_now();
+	mark("g:fill");
 	if ((rc = gd_host_grow(ctx, ctx->h_res, sizeof(int32_t) * 2 * (size_t)std::max(nb, 1)))) return rc;
 	int32_t *h_score = (int32_t *)ctx->h_res.p, *h_ncig = h_score + nb;
 	uint32_t *h_cig = nullptr;
@@ -526,6 +550,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		                      qoff.data(), toff.data(), bw.data(), sd, coff.data(), ex.data(), ctx->parent ? ctx->parent->arena_ev : nullptr,
 		                      ctx->parent ? &dp_lock : nullptr);
 		if (rc) return rc; // (the lock, if taken, is released by dp_lock's destructor)
+	mark("d:plan+enqueue");
 		if (ctx->parent) {
 			if (!ctx->own_arena) GD_HIP(hipEventRecord(ctx->parent->arena_ev, sd)); // the backtrack is done by then: the CIGARs sit in this lane's own buffer
 			if (dp_lock.owns_lock()) dp_lock.unlock();
@@ -533,6 +558,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		GD_HIP(hipMemcpyAsync(h_score, d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipMemcpyAsync(h_ncig, d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipStreamSynchronize(sd));
+	mark("d:wait");
 		// CIGARs are short compared with their capacity (qlen+tlen): pack them on the device, then one copy
 		for (int b = 0; b < nb; ++b) if (h_ncig[b] > coff[b + 1] - coff[b]) { ctx->err = "CIGAR capacity exceeded"; return GDIET_E_CIGAR_CAP; }
 		poff.assign(nb + 1, 0);
@@ -551,6 +577,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	}
 	if (dp_lock.owns_lock()) dp_lock.unlock();
 	ctx->stage_s[3] += gd_now() - t0, t0 = gd_now();
+	mark("d:pack");
 	// ---- P1-P3 (host threads) ---------------------------------------------------------------------------------------------
 	static std::atomic<uint64_t> call_counter{0};
 	const uint64_t call_id = ++call_counter; // names the slabs of this call (GdRegSlab)
@@ -559,15 +586,18 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		n_regs[i] = 0, regs[i] = nullptr;
 		const size_t nc = (size_t)ccount[i];
 		if (!nc) return;
-		std::vector<GdCand> C(nc); // the records grow CIGARs: this thread's copy
+		// scratch of the worker thread, reused from read to read (the workers are persistent)
+		static thread_local std::vector<GdCand> C;
+		static thread_local std::vector<uint8_t> rev;
+		static thread_local std::vector<GdDpResult> dp;
+		C.assign(nc, GdCand()); // the records grow CIGARs: this thread's copy
 		for (size_t j = 0; j < nc; ++j) gd_cand_unbox(cflat[(size_t)cfirst[i] + j], C[j]);
 		const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
 		const uint8_t *enc = B.enc + B.roff[i];
-		std::vector<uint8_t> rev;
 		bool need_rev = false;
 		for (auto &c : C) need_rev |= c.v.str != 0;
 		if (need_rev) { rev.resize(rl); for (uint32_t j = 0; j < rl; ++j) rev[rl - 1 - j] = enc[j] ^ 3; }
-		std::vector<GdDpResult> dp(nc);
+		dp.resize(nc);
 		for (size_t j = 0; j < nc; ++j) {
 			const int b = box_first[i] + (int)j;
 			dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig + poff[b];
@@ -583,6 +613,8 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	});
 	if (no_mem.load()) { gdiet_hip_free_regs(n, n_regs, regs); ctx->err = "out of host memory for the records"; return GDIET_E_NOMEM; }
 	ctx->stage_s[4] += gd_now() - t0;
+	mark("post");
+	if (trace) fprintf(stderr, "[gdiet stages, ms] n=%d%s\n", n, tr_s.c_str());
 	return GDIET_OK;
 }
 
