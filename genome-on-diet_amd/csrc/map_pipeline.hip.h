@@ -602,7 +602,8 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			const int b = box_first[i] + (int)j;
 			dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig + poff[b];
 		}
-		std::vector<GdReg> out;
+		static thread_local std::vector<GdReg> out;
+		out.clear();
 		if (is_sr) gd_sr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
 		else gd_lr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
 		if (out.empty()) return;
