@@ -17,7 +17,8 @@ struct MapDevOpt { // uniform per batch
 	int64_t flag;
 	GdLrVoteOpt vote;
 	GdSrVoteOpt sr;    // ShortReads variant (flag & MM_F_SR)
-	int32_t is_sr, pad;
+	int32_t is_sr;
+	int32_t sort_cap;  // hashes of one read the wave seed kernel sorts in LDS (a power of two; the launch provides 8 B each)
 	GdPattern pat;
 };
 
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(64) void map_pack_cigar_kernel(int nb, const uint32
 // The winnowing automaton is sequential, but exact slices of it can be produced independently (gd_sketch_slice), so the 64
 // lanes sketch 64 slices of the read, compact their minimizers in read order with a wavefront prefix sum, probe the index
 // in parallel, and leave only the short sequential parts (query-occurrence filter, high-occurrence seed selection) to lane 0.
-#define MAP_SORT_CAP 2048 // hashes of one read the seed kernel sorts in LDS (16 KB)
+#define MAP_SORT_CAP 2048      // hashes of one read the seed kernel sorts in LDS: at least (16 KB) ...
+#define MAP_SORT_CAP_MAX 16384 // ... and at most (128 KB: ONT reads of up to ~180 kbp), chosen per batch from its longest read
 
 struct GdEmitLane { // per-lane emission list in scratch
 	GdMini *out;
@@ -382,11 +384,11 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	// S4: mm_seed_mz_flt.  It only ever drops something when one hash occurs more than mid_occ times in the read, which a
 	// wavefront bitonic sort of the hashes in LDS decides in a few microseconds (a run longer than mid_occ <=> s[i] == s[i + mid_occ]
 	// for some i); only then -- practically never -- does lane 0 run the sequential filter.  Lists too long for the LDS buffer
-	// (ONT reads) take the sequential path directly.
+	// (O.sort_cap, sized by the host for the longest read of the batch, at most MAP_SORT_CAP_MAX) take the sequential path directly.
 	if (O.q_occ_frac > 0.0f && (int64_t)n_mv > (int64_t)O.mid_occ && O.mid_occ > 0) {
 		uint64_t *srt = reinterpret_cast<uint64_t *>(seed_lds); // the window storage is idle now
 		bool need = true;
-		if (n_mv <= MAP_SORT_CAP) {
+		if (n_mv <= (unsigned)O.sort_cap) {
 			unsigned P2 = 64;
 			while (P2 < n_mv) P2 <<= 1;
 			for (unsigned i = lane; i < P2; i += 64) srt[i] = i < n_mv ? mv[i].x : UINT64_MAX;

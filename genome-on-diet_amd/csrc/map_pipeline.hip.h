@@ -390,7 +390,15 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	D.vote.vt_dis = O.vt_dis, D.vote.vt_nb_loc = O.vt_nb_loc, D.vote.bw = O.bw, D.vote.vt_cov = O.vt_cov, D.vote.vt_f = O.vt_f;
 	D.vote.vt_df1 = O.vt_df1, D.vote.vt_df2 = O.vt_df2, D.vote.k = O.k;
 	const bool is_sr = (O.flag & GD_F_SR) != 0;
-	D.is_sr = is_sr, D.pad = 0;
+	D.is_sr = is_sr;
+	{ // LDS sort capacity of the wave seed kernel: ~1.25 x the minimizers expected of the longest read (2 / (w + 1) of its sparsified bases)
+		int64_t max_len = 0;
+		for (int i = 0; i < n; ++i) max_len = std::max<int64_t>(max_len, B.roff[i + 1] - B.roff[i]);
+		const double est = 1.25 * 2.0 / (O.w + 1) * gd_diet_len(O.pat, (unsigned)max_len, 0);
+		int cap = MAP_SORT_CAP;
+		while (cap < MAP_SORT_CAP_MAX && cap < est) cap <<= 1;
+		D.sort_cap = cap;
+	}
 	D.sr.min_cnt = O.min_cnt, D.sr.rec_threshold_frac = O.rec_threshold_frac, D.sr.bw_frac = O.bw_frac, D.sr.bw_min = O.bw_min, D.sr.bw_max = O.bw_max;
 	D.sr.af_max_loc = O.af_max_loc, D.sr.max_nb_seeds = D.max_nb_seeds, D.sr.frag_mode = (O.flag & GD_F_FRAG_MODE) != 0;
 	const uint8_t *d_reads = (const uint8_t *)B.d_reads;
@@ -399,6 +407,8 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// ---- S1-S5 ----------------------------------------------------------------------------------------------------
 	if ((rc = gd_host_grow(ctx, ctx->h_seedout, sizeof(MapSeedOut) * (size_t)n))) return rc;
 	MapSeedOut *so = (MapSeedOut *)ctx->h_seedout.p;
+	const size_t seed_lds = std::max<size_t>((size_t)O.w * 64 * sizeof(GdMini), (size_t)D.sort_cap * sizeof(uint64_t));
+	if (seed_lds > 64 * 1024) GD_HIP(hipFuncSetAttribute((const void *)map_seed_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seed_lds));
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		// one read per thread (the plain sequential form) for short reads -- a 150 bp read has ~75 sparsified bases, far too few to
 		// split over 64 lanes (measured 18x faster at 150 bp) -- and on request (GDIET_SEED_KERNEL=thread) for A/B checks
@@ -406,7 +416,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 		else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
-			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), std::max<size_t>((size_t)O.w * 64 * sizeof(GdMini), MAP_SORT_CAP * sizeof(uint64_t)), s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), seed_lds, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 		GD_HIP(hipMemcpyAsync(so, ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
 		GD_HIP(hipStreamSynchronize(s));
