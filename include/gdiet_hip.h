@@ -216,7 +216,9 @@ void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *batch);
  * gdiet_hip_set_inflight() tickets (default 2, at most 4) may be open; wait for them in submission order.  The latency-bound
  * stages of one batch overlap the DP kernel of another, exactly as the reference's kt_pipeline overlaps the steps of consecutive
  * mini-batches (LR/map.c:2094-2170); results are those of gdiet_hip_map_uploaded.  The lanes share one backtrace arena (~34 MB
- * per 15 kbp alignment: two whole-batch arenas would not fit in HBM), so their DP stages take turns. */
+ * per 15 kbp alignment: two whole-batch arenas would not fit in HBM), so their DP stages take turns -- unless a batch's backtrace
+ * is small enough for every lane to hold one of its own (gdiet_hip_set_inflight sets the limit: 70 % of HBM / n, or
+ * GDIET_LANE_ARENA_GB), in which case the DP kernels of the batches in flight overlap as well. */
 typedef struct gdiet_map_ticket gdiet_map_ticket;
 int gdiet_hip_set_inflight(gdiet_ctx *ctx, int n);
 int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, gdiet_read_batch *batch,
