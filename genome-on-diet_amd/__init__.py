@@ -9,4 +9,5 @@ The directory name carries a hyphen, so import it with ``importlib`` (see ``test
 """
 from .hip_abi import Context, GdietError, KswScore, library_path, load_library, pack, PRESET_SCORES  # noqa: F401
 from .map_api import Mapper, MapOpt, PRESETS as MAP_PRESETS  # noqa: F401,E402
+from .fastx import FastxReader  # noqa: F401,E402
 from .shard import JobClock, effective_cpus, rank_seed, read_range, read_ranges_by_cost  # noqa: F401,E402

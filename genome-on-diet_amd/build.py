@@ -19,7 +19,7 @@ def build_hip(force=False, verbose=False):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB, SRC, "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -711,3 +711,39 @@ extern "C" int gdiet_hip_ksw_extz2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 }
 
 #include "map_pipeline.hip.h"
+
+// ---- read input (input half) ---------------------------------------------------------------------------
+#include "fastx_reader.h"
+struct gdiet_fastx { GdFastx *r; };
+
+extern "C" int gdiet_hip_fastx_open(gdiet_fastx **fx, const char *path)
+{
+	if (!fx) return GDIET_E_PARAM;
+	*fx = nullptr;
+	GdFastx *r = gd_fastx_open(path);
+	if (!r) return GDIET_E_PARAM;
+	*fx = new gdiet_fastx{r};
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_fastx_read(gdiet_fastx *fx, int64_t chunk_size, int with_qual, int with_comment, int frag_mode, int32_t *n_reads,
+                                    const char *const **names, const char *const **comments, const char *const **seqs,
+                                    const char *const **quals, const int32_t **lens)
+{
+	if (!fx || !fx->r || !n_reads || !names || !seqs || !lens) return GDIET_E_PARAM;
+	bool bad = false;
+	const int n = fx->r->read_batch(chunk_size, with_qual != 0, with_comment != 0, frag_mode != 0, &bad);
+	if (n < 0) return GDIET_E_PARAM;
+	*n_reads = n;
+	*names = fx->r->v_name.data(), *seqs = fx->r->v_seq.data(), *lens = fx->r->v_len.data();
+	if (comments) *comments = fx->r->v_comment.data();
+	if (quals) *quals = fx->r->v_qual.data();
+	return bad ? GDIET_W_TRUNCATED : GDIET_OK;
+}
+
+extern "C" void gdiet_hip_fastx_close(gdiet_fastx *fx)
+{
+	if (!fx) return;
+	gd_fastx_close(fx->r);
+	delete fx;
+}

@@ -249,6 +249,22 @@ size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *idx, int n_reads, 
                            const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
                            int64_t opt_flag, char **out);
 
+/* Read input, step 0 of worker_pipeline (LR/map.c:2095-2131): FASTA / FASTQ, plain or gzip ("-" = stdin), one mini-batch per
+ * call.  Replaces mm_bseq_open / mm_bseq_read3 / mm_bseq_close (LR/bseq.c:38-58, 80-121) with the same record grammar
+ * (kseq_read, LR/kseq.h:191-232: multi-line records, names up to the first white space, the rest of the header as comment,
+ * "\r\n" line ends, U -> T) and the same batching rule (records until their lengths sum to chunk_size; in fragment mode the mates
+ * of the last read as well).  The arrays and strings belong to the reader and stay valid until the next call on it; comments[i]
+ * and quals[i] are NULL where the reference would store none.  *n_reads == 0: end of input.  Returns GDIET_OK, or
+ * GDIET_W_TRUNCATED when the input ended in a malformed record (the batch holds the records before it; the reference prints a
+ * warning and goes on likewise), or GDIET_E_PARAM (cannot open / read error). */
+#define GDIET_W_TRUNCATED 1
+typedef struct gdiet_fastx gdiet_fastx;
+int gdiet_hip_fastx_open(gdiet_fastx **fx, const char *path);
+int gdiet_hip_fastx_read(gdiet_fastx *fx, int64_t chunk_size, int with_qual, int with_comment, int frag_mode, int32_t *n_reads,
+                         const char *const **names, const char *const **comments, const char *const **seqs,
+                         const char *const **quals, const int32_t **lens);
+void gdiet_hip_fastx_close(gdiet_fastx *fx);
+
 #ifdef __cplusplus
 }
 #endif
