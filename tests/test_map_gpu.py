@@ -272,3 +272,25 @@ def test_three_batches_in_flight_short_reads(gpu_ctx, pkg):
             m.free_batch(b)
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("kind", ["hifi", "sr"])
+def test_file_to_sam_through_the_library(gpu_ctx, pkg, kind):
+    """steps 0-2 of the reference's worker_pipeline through the C ABI alone: gdiet_hip_fastx_read (mini-batches of the FASTQ file)
+    -> map -> gdiet_hip_sam_batch; the concatenation is the golden SAM body, whatever the mini-batch size"""
+    base, stem, preset = SETS[kind]
+    names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset=preset, **OVERRIDES.get(kind, {}))
+    try:
+        for chunk in (60000, 10 ** 9):
+            out = []
+            with pkg.FastxReader(os.path.join(base, stem + ".fq.gz")) as r:
+                while True:
+                    b = r.read(chunk)
+                    if not b:
+                        break
+                    res = m.map([x[1] for x in b])
+                    out.append(m.sam_batch(res, [(x[0], x[1], x[2]) for x in b]))
+            assert "".join(out) == "".join(l + "\n" for l in golden_sam(kind))
+    finally:
+        m.close()
