@@ -9,45 +9,28 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
+#include <deque>
+#include <memory>
+#include <thread>
 #include <vector>
 #include <zlib.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <unistd.h>
 
-struct GdFastx {
-	gzFile fp = nullptr; // gzip input, or stdin
-	int fd = -1;         // plain file: read() straight into the buffer (gzread would copy it once more)
-	std::vector<unsigned char> buf;
+// Record parser over a byte range held in memory (kseq_read's grammar); the reader below feeds it blocks of the file.
+struct GdFastxParser {
+	const unsigned char *b = nullptr;
 	size_t begin = 0, end = 0;
-	bool eof = false, io_error = false;
+	bool eof = false;  // ran off the end of the range (kseq's end-of-file behaviour applies from then on)
 	int last_char = 0; // kseq_t::last_char: the header character of the next record has been consumed already
-	// the record read ahead by the fragment-mode pairing rule (mm_bseq_file_t::s): name, comment, seq, qual
-	bool have_pending = false;
-	std::string pending[4];
-	// the batch being built / handed out last: every string in `arena` (NUL-terminated), 4 offsets per read (name, comment, seq,
-	// qual; -1 = absent).  Records are parsed straight into the arena.
-	std::string arena, scratch;
-	std::vector<int64_t> off;
-	std::vector<const char *> v_name, v_comment, v_seq, v_qual;
-	std::vector<int32_t> v_len;
-
-	bool fill()
-	{
-		if (eof) return false;
-		begin = 0;
-		long n;
-		if (fd >= 0) {
-			do n = (long)::read(fd, buf.data(), buf.size()); while (n < 0 && errno == EINTR);
-		} else n = gzread(fp, buf.data(), (unsigned)buf.size());
-		if (n <= 0) { eof = true, end = 0; if (n < 0) io_error = true; return false; }
-		end = (size_t)n;
-		return true;
-	}
+	std::string arena, scratch; // every string of the parsed records, NUL-terminated
+	bool fill() { eof = true; return false; }
 	int getc_()
 	{
 		if (begin >= end && !fill()) return -1;
-		return buf[begin++];
+		return b[begin++];
 	}
 	// ks_getuntil2 (LR/kseq.h:102-149) for KS_SEP_LINE (line = true) and KS_SEP_SPACE, appending to s, whose current field starts
 	// at `base`; returns the length of the field, or -1 at the end of the file with nothing read
@@ -59,18 +42,18 @@ struct GdFastx {
 			if (begin >= end && !fill()) break;
 			size_t i;
 			if (line) {
-				const void *p = memchr(buf.data() + begin, '\n', end - begin);
-				i = p ? (size_t)((const unsigned char *)p - buf.data()) : end;
+				const void *p = memchr(b + begin, '\n', end - begin);
+				i = p ? (size_t)((const unsigned char *)p - b) : end;
 			} else {
 				for (i = begin; i < end; ++i) {
-					const unsigned char c = buf[i];
+					const unsigned char c = b[i];
 					if (c == ' ' || (c >= '\t' && c <= '\r')) break; // isspace() in the C locale
 				}
 			}
 			gotany = true;
-			s.append((const char *)buf.data() + begin, i - begin);
+			s.append((const char *)b + begin, i - begin);
 			begin = i + 1;
-			if (i < end) { if (dret) *dret = buf[i]; break; }
+			if (i < end) { if (dret) *dret = b[i]; break; }
 		}
 		if (!gotany && eof) return -1;
 		if (line && s.size() - base > 1 && s.back() == '\r') s.pop_back();
@@ -119,70 +102,205 @@ struct GdFastx {
 		else arena.resize(qs);
 		return (long)l_seq;
 	}
+};
+
+// The parsed records of one stretch of the file, in file order
+struct GdFastxChunk {
+	std::string arena;
+	std::vector<int64_t> off;     // 4 per record: name, comment, seq, qual (-1 = none)
+	std::vector<int32_t> len;     // sequence length per record
+	std::vector<uint8_t> err;     // per record: a malformed record (kseq_read < -1) FOLLOWED this one ...
+	bool err_first = false;       // ... or preceded the first one
+	size_t next = 0;              // records handed out so far
+};
+
+struct GdFastx {
+	gzFile fp = nullptr; // gzip input, or stdin
+	int fd = -1;         // plain file: read() straight into the block (gzread would copy it once more)
+	bool file_end = false, io_error = false;
+	int n_threads = 1;
+	size_t block_size = (size_t)8 << 20; // per parser thread
+	std::vector<unsigned char> block;    // [0, fill): unparsed tail of the previous block + fresh bytes
+	size_t fill = 0;
+	std::deque<std::unique_ptr<GdFastxChunk>> ready; // parsed, not yet (completely) handed out
+	std::vector<std::unique_ptr<GdFastxChunk>> lent; // handed out by the last call: alive until the next one
+	bool with_qual = true, with_comment = false, flags_set = false;
+	std::vector<const char *> v_name, v_comment, v_seq, v_qual;
+	std::vector<int32_t> v_len;
+
 	static size_t qname_len(const char *s) // mm_qname_len (LR/bseq.h:30-36)
 	{
 		const size_t l = strlen(s);
 		return l >= 3 && s[l - 1] >= '0' && s[l - 1] <= '9' && s[l - 2] == '/' ? l - 2 : l;
 	}
-	void keep(const int64_t o[4], long l_seq)
+	bool read_more(size_t want)
 	{
-		off.insert(off.end(), o, o + 4);
-		v_len.push_back((int32_t)l_seq);
+		if (file_end) return false;
+		if (block.size() < fill + want) block.resize(fill + want);
+		size_t got = 0;
+		while (got < want) {
+			long n;
+			if (fd >= 0) {
+				do n = (long)::read(fd, block.data() + fill + got, want - got); while (n < 0 && errno == EINTR);
+			} else n = gzread(fp, block.data() + fill + got, (unsigned)std::min<size_t>(want - got, (size_t)1 << 30));
+			if (n < 0) { io_error = true, file_end = true; break; }
+			if (n == 0) { file_end = true; break; }
+			got += (size_t)n;
+		}
+		fill += got;
+		return got > 0;
+	}
+	// Parse block[from, fill) sequentially into C, never starting a record at or after `stop` (the next parser's first record, or
+	// `fill`).  Returns where the next record would start: exactly `stop` when the stretch ends on the seam (or the range is
+	// exhausted); something else tells the caller that the seam was not a record boundary.  A record cut off by the end of the
+	// block (more of the file to come) is not parsed: its start is returned.
+	size_t parse_range(GdFastxChunk &C, size_t from, size_t stop, bool last_of_file) const
+	{
+		GdFastxParser P;
+		P.b = block.data(), P.end = fill;
+		size_t pos = from;
+		P.arena.swap(C.arena);
+		for (;;) {
+			// the header scan of kseq_read: the next '>' or '@', wherever it stands
+			size_t h = pos;
+			while (h < fill && block[h] != '>' && block[h] != '@') ++h;
+			if (h >= stop) { pos = h >= fill ? fill : h; break; } // (h == stop: the seam; h > stop: not a boundary, the caller sees it)
+			P.begin = h, P.eof = false, P.last_char = 0;
+			int64_t o[4];
+			const long r = P.read_record(with_qual, with_comment, o);
+			if (P.eof && !last_of_file) { pos = h; P.arena.resize(o[0] >= 0 && (size_t)o[0] <= P.arena.size() && r >= 0 ? (size_t)o[0] : P.arena.size()); break; } // cut off by the block end
+			size_t e = P.begin;
+			if (P.last_char) --e; // the next header character was consumed: hand it back
+			if (r >= 0) C.off.insert(C.off.end(), o, o + 4), C.len.push_back((int32_t)r), C.err.push_back(0);
+			else if (r < -1) { if (C.len.empty()) C.err_first = true; else C.err.back() = 1; }
+			pos = e;
+			if (r == -1 || e >= fill) { pos = std::min(e, fill); if (r == -1) pos = fill; break; }
+		}
+		P.arena.swap(C.arena);
+		return pos;
+	}
+	// a position in (from, fill) that looks like the first byte of a four-line FASTQ record
+	size_t find_seam(size_t from) const
+	{
+		const unsigned char *b = block.data();
+		for (size_t p = from; p < fill;) {
+			const void *nl = memchr(b + p, '\n', fill - p);
+			if (!nl) return fill;
+			size_t q = (size_t)((const unsigned char *)nl - b) + 1; // start of a line
+			if (q >= fill) return fill;
+			if (b[q] == '@') {
+				const void *e1 = memchr(b + q, '\n', fill - q);
+				if (!e1) return fill;
+				const size_t l2 = (size_t)((const unsigned char *)e1 - b) + 1;
+				const void *e2 = l2 < fill ? memchr(b + l2, '\n', fill - l2) : nullptr;
+				if (!e2) return fill;
+				const size_t l3 = (size_t)((const unsigned char *)e2 - b) + 1;
+				if (l3 < fill && b[l3] == '+') {
+					const void *e3 = memchr(b + l3, '\n', fill - l3);
+					if (!e3) return fill;
+					const size_t l4 = (size_t)((const unsigned char *)e3 - b) + 1;
+					const void *e4 = l4 < fill ? memchr(b + l4, '\n', fill - l4) : nullptr;
+					if (e4 && (size_t)((const unsigned char *)e4 - b) - l4 == l3 - 1 - l2) return q;
+				}
+			}
+			p = q;
+		}
+		return fill;
+	}
+	// read and parse one more block; false when the input is exhausted
+	bool parse_more()
+	{
+		size_t want = block_size * (size_t)n_threads;
+		for (;;) {
+			const bool got = read_more(want);
+			if (fill == 0) return false;
+			// split points: record starts verified by look-ahead; whether they ARE boundaries of the sequential grammar is checked
+			// afterwards (every stretch must end exactly where the next one began) -- if not, the rest is parsed again in sequence
+			std::vector<size_t> cut(1, 0);
+			if (n_threads > 1 && fill >= std::min<size_t>((size_t)1 << 20, block_size))
+				for (int k = 1; k < n_threads; ++k) {
+					const size_t c = find_seam(std::max(cut.back() + 1, fill / (size_t)n_threads * (size_t)k));
+					if (c >= fill) break;
+					cut.push_back(c);
+				}
+			const size_t nr = cut.size();
+			std::vector<std::unique_ptr<GdFastxChunk>> parts(nr);
+			std::vector<size_t> endpos(nr, 0);
+			auto work = [&](size_t k) {
+				parts[k].reset(new GdFastxChunk());
+				endpos[k] = parse_range(*parts[k], cut[k], k + 1 < nr ? cut[k + 1] : fill, file_end);
+			};
+			if (nr > 1) {
+				std::vector<std::thread> th;
+				for (size_t k = 1; k < nr; ++k) th.emplace_back(work, k);
+				work(0);
+				for (auto &t : th) t.join();
+			} else work(0);
+			size_t good = 1; // stretches [0, good) are what a sequential parse would have produced
+			while (good < nr && endpos[good - 1] == cut[good]) ++good;
+			size_t pos = endpos[good - 1];
+			if (good < nr) { // a seam was no boundary: everything after the last good stretch again, in sequence
+				parts.resize(good + 1);
+				parts[good].reset(new GdFastxChunk());
+				pos = parse_range(*parts[good], endpos[good - 1], fill, file_end);
+			}
+			size_t n_rec = 0;
+			for (auto &c : parts) if (c) { n_rec += c->len.size() + (c->err_first ? 1 : 0); if (!c->len.empty() || c->err_first) ready.push_back(std::move(c)); }
+			// keep the unparsed tail (a record cut off by the block end) for the next round
+			memmove(block.data(), block.data() + pos, fill - pos);
+			fill -= pos;
+			if (n_rec) return true;
+			if (file_end) { fill = 0; return false; } // (only separators / a malformed rest were left)
+			if (!got && fill == 0) return false;
+			want *= 2; // a record longer than the block: read on
+		}
 	}
 	// mm_bseq_read3 (LR/bseq.c:80-121); returns the number of reads of the batch (0 at the end of the file), < 0 on a read error
-	int read_batch(int64_t chunk_size, bool with_qual, bool with_comment, bool frag_mode, bool *parse_error)
+	int read_batch(int64_t chunk_size, bool wq, bool wc, bool frag_mode, bool *parse_error)
 	{
-		arena.clear(), off.clear(), v_len.clear();
+		if (!flags_set) with_qual = wq, with_comment = wc, flags_set = true; // (the flags of the first call hold for the whole file)
+		lent.clear();
+		v_name.clear(), v_comment.clear(), v_seq.clear(), v_qual.clear(), v_len.clear();
 		if (parse_error) *parse_error = false;
-		int64_t size = 0, o[4];
-		long ret = 0;
-		if (have_pending) { // (read with the flags of the call that looked ahead, as in the reference)
-			for (int k = 0; k < 4; ++k) {
-				const bool present = k == 0 || k == 2 || !pending[k].empty();
-				o[k] = present ? (int64_t)arena.size() : -1;
-				if (present) arena.append(pending[k]), arena.push_back('\0');
+		int64_t size = 0;
+		bool closing = false; // the batch is full: only mates of its last read may still join (fragment mode)
+		for (;;) {
+			while (!ready.empty() && ready.front()->next >= ready.front()->len.size() && !ready.front()->err_first) lent.push_back(std::move(ready.front())), ready.pop_front();
+			if (ready.empty() && !parse_more()) break;
+			if (ready.empty()) continue;
+			GdFastxChunk &C = *ready.front();
+			if (C.err_first) { C.err_first = false; if (parse_error) *parse_error = true; break; } // the reference warns and returns what it has
+			if (C.next >= C.len.size()) continue;
+			const size_t i = C.next;
+			const char *nm = C.arena.data() + C.off[4 * i];
+			if (closing) {
+				const char *prev = v_name.back();
+				const size_t l1 = qname_len(nm), l2 = qname_len(prev);
+				if (!(l1 == l2 && strncmp(nm, prev, l1) == 0)) break;
 			}
-			keep(o, (long)pending[2].size());
-			size = (int64_t)pending[2].size(), have_pending = false;
-		}
-		while ((ret = read_record(with_qual, with_comment, o)) >= 0) {
-			keep(o, ret);
-			size += ret;
-			if (size >= chunk_size) {
-				if (frag_mode && ret < 1000000) { // CHECK_PAIR_THRES: keep the mates of the last read in this batch
-					while ((ret = read_record(with_qual, with_comment, o)) >= 0) {
-						const char *prev = arena.data() + off[off.size() - 4], *cur = arena.data() + o[0];
-						const size_t l1 = qname_len(cur), l2 = qname_len(prev);
-						if (l1 == l2 && strncmp(cur, prev, l1) == 0) keep(o, ret);
-						else { // belongs to the next batch: take it out of this arena again
-							for (int k = 0; k < 4; ++k) pending[k] = o[k] < 0 ? std::string() : std::string(arena.data() + o[k]);
-							arena.resize((size_t)o[0]);
-							have_pending = true;
-							break;
-						}
-					}
-				}
-				break;
+			v_name.push_back(nm);
+			v_comment.push_back(C.off[4 * i + 1] < 0 ? nullptr : C.arena.data() + C.off[4 * i + 1]);
+			v_seq.push_back(C.arena.data() + C.off[4 * i + 2]);
+			v_qual.push_back(C.off[4 * i + 3] < 0 ? nullptr : C.arena.data() + C.off[4 * i + 3]);
+			v_len.push_back(C.len[i]);
+			size += C.len[i];
+			++C.next;
+			if (C.err[i]) { C.err[i] = 0; if (parse_error) *parse_error = true; break; }
+			if (!closing && size >= chunk_size) {
+				if (frag_mode && C.len[i] < 1000000) closing = true; // CHECK_PAIR_THRES
+				else break;
 			}
 		}
-		if (ret < -1 && parse_error) *parse_error = true; // the reference warns and goes on with what it has
+		// (pointers into chunks still in `ready` stay valid: a chunk is only released from `lent`, at the next call)
 		if (io_error) return -1;
-		const size_t n = v_len.size();
-		v_name.resize(n), v_comment.resize(n), v_seq.resize(n), v_qual.resize(n);
-		for (size_t i = 0; i < n; ++i) {
-			v_name[i] = arena.data() + off[4 * i];
-			v_comment[i] = off[4 * i + 1] < 0 ? nullptr : arena.data() + off[4 * i + 1];
-			v_seq[i] = arena.data() + off[4 * i + 2];
-			v_qual[i] = off[4 * i + 3] < 0 ? nullptr : arena.data() + off[4 * i + 3];
-		}
-		return (int)n;
+		return (int)v_len.size();
 	}
 };
 
 static inline GdFastx *gd_fastx_open(const char *path)
 {
 	GdFastx *fx = new GdFastx();
-	fx->buf.resize(4 << 20);
+	if (const char *e = getenv("GDIET_FASTX_BLOCK")) fx->block_size = std::max<size_t>(256, (size_t)atol(e)); // (tests: many small blocks)
 	if (path && strcmp(path, "-")) { // a plain file is read directly, anything that starts with the gzip magic through zlib
 		const int fd = ::open(path, O_RDONLY);
 		if (fd < 0) { delete fx; return nullptr; }

@@ -741,6 +741,13 @@ extern "C" int gdiet_hip_fastx_read(gdiet_fastx *fx, int64_t chunk_size, int wit
 	return bad ? GDIET_W_TRUNCATED : GDIET_OK;
 }
 
+extern "C" int gdiet_hip_fastx_set_threads(gdiet_fastx *fx, int n)
+{
+	if (!fx || !fx->r || n < 1 || n > 64) return GDIET_E_PARAM;
+	fx->r->n_threads = n;
+	return GDIET_OK;
+}
+
 extern "C" void gdiet_hip_fastx_close(gdiet_fastx *fx)
 {
 	if (!fx) return;

@@ -8,7 +8,7 @@ W_TRUNCATED = 1
 
 
 class FastxReader:
-    def __init__(self, path):
+    def __init__(self, path, threads=1):
         self.lib = load_library()
         L = self.lib
         cpp = C.POINTER(C.c_char_p)
@@ -20,7 +20,10 @@ class FastxReader:
         self._h = C.c_void_p()
         if L.gdiet_hip_fastx_open(C.byref(self._h), path.encode() if isinstance(path, str) else path) != 0:
             raise GdietError("cannot open %r" % (path,))
-        self.truncated = False
+        self.truncated = self.truncated_now = False
+        L.gdiet_hip_fastx_set_threads.argtypes = [C.c_void_p, C.c_int]
+        if threads > 1:
+            L.gdiet_hip_fastx_set_threads(self._h, threads)
 
     def read(self, chunk_size, with_qual=True, with_comment=False, frag_mode=False):
         """next mini-batch as a list of (name, seq, qual or None, comment or None), all bytes; [] at the end of the input"""
@@ -31,7 +34,8 @@ class FastxReader:
                                            C.byref(comments), C.byref(seqs), C.byref(quals), C.byref(lens))
         if rc < 0:
             raise GdietError("read error")
-        self.truncated = self.truncated or rc == W_TRUNCATED
+        self.truncated_now = rc == W_TRUNCATED  # this batch was closed by a malformed record
+        self.truncated = self.truncated or self.truncated_now
         out = []
         for i in range(n.value):
             s = seqs[i]

@@ -254,7 +254,8 @@ size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *idx, int n_reads, 
  * (kseq_read, LR/kseq.h:191-232: multi-line records, names up to the first white space, the rest of the header as comment,
  * "\r\n" line ends, U -> T) and the same batching rule (records until their lengths sum to chunk_size; in fragment mode the mates
  * of the last read as well).  The arrays and strings belong to the reader and stay valid until the next call on it; comments[i]
- * and quals[i] are NULL where the reference would store none.  *n_reads == 0: end of input.  Returns GDIET_OK, or
+ * and quals[i] are NULL where the reference would store none; with_qual / with_comment of the FIRST call hold for the whole file
+ * (the reader parses ahead).  *n_reads == 0: end of input.  Returns GDIET_OK, or
  * GDIET_W_TRUNCATED when the input ended in a malformed record (the batch holds the records before it; the reference prints a
  * warning and goes on likewise), or GDIET_E_PARAM (cannot open / read error). */
 #define GDIET_W_TRUNCATED 1
@@ -263,6 +264,10 @@ int gdiet_hip_fastx_open(gdiet_fastx **fx, const char *path);
 int gdiet_hip_fastx_read(gdiet_fastx *fx, int64_t chunk_size, int with_qual, int with_comment, int frag_mode, int32_t *n_reads,
                          const char *const **names, const char *const **comments, const char *const **seqs,
                          const char *const **quals, const int32_t **lens);
+/* parser threads (default 1).  Blocks of the file are cut at places that look like the start of a four-line FASTQ record and the
+ * stretches parsed side by side; a stretch that does not end exactly where the next one began proves the cut wrong, and the rest of
+ * the block is parsed again in sequence -- so the records are those of the sequential grammar whatever the input looks like. */
+int gdiet_hip_fastx_set_threads(gdiet_fastx *fx, int n);
 void gdiet_hip_fastx_close(gdiet_fastx *fx);
 
 #ifdef __cplusplus

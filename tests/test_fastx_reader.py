@@ -61,6 +61,9 @@ def _awkward_inputs(rng):
     files["multi.fa"] = b"".join(recs).rstrip(b"\n")
     # 5. FASTQ whose last record has a short quality string
     files["truncated.fq"] = files["plain.fq"][:2000].rsplit(b"@r", 1)[0] + b"@last\nACGTACGTACGT\n+\nIIII\n"
+    # 6. a malformed record in the middle: the lines after it are swallowed / rescanned exactly as kseq_read does
+    body = files["plain.fq"].split(b"\n@r")
+    files["broken_mid.fq"] = b"\n@r".join(body[:12]) + b"\n@bad\nACGTACGTAC\n+\nII\n@r" + b"\n@r".join(body[12:])
     return files
 
 
@@ -89,9 +92,9 @@ def _ours(pkg, path, chunk, with_comment):
     with pkg.FastxReader(path) as r:
         while True:
             b = r.read(chunk, with_qual=True, with_comment=with_comment)
-            if not b:
+            if not b and not r.truncated_now:
                 break
-            sizes.append([len(x[1]) for x in b])
+            sizes.append(([len(x[1]) for x in b], r.truncated_now))
             rows += b
         trunc = r.truncated
     return rows, sizes, trunc
@@ -123,10 +126,10 @@ def test_reader_matches_the_reference_parser(tmp_path, with_comment):
                 with open(gold) as f:
                     want = [tuple(x.encode("latin1") if x is not None else None for x in row) for row in json.load(f)]
             assert _norm(ours, with_comment) == [tuple(w) for w in want], (name, gz)
-            assert trunc == (name == "truncated.fq")
+            assert trunc == (name in ("truncated.fq", "broken_mid.fq"))
             # mm_bseq_read3's batching rule: a batch closes with the record that brings its bases to chunk_size
-            for b in sizes[:-1]:
-                assert sum(b) >= 1500 and sum(b[:-1]) < 1500
+            for b, closed_early in sizes[:-1]:  # (a malformed record closes its batch early, as in the reference)
+                assert closed_early or (sum(b) >= 1500 and sum(b[:-1]) < 1500)
 
 
 def test_fragment_mode_keeps_mates_together(tmp_path):
@@ -172,3 +175,53 @@ def test_reader_feeds_the_mapper_like_the_reference(tmp_path):
         if flag & 16:
             s, q = s.translate(comp)[::-1], q[::-1]
         assert sam_seq == s.decode() and sam_qual == q.decode()
+
+
+@pytest.mark.parametrize("block", [4096, 65536, 8 << 20])
+def test_parallel_parse_equals_sequential_parse(tmp_path, block, monkeypatch):
+    """several parser threads on speculative cuts give the records of the sequential grammar: a file of four-line FASTQ whose
+    quality lines start with '@' and '+', with stretches of multi-line FASTQ, Windows line ends, FASTA and a malformed record in
+    between (cuts that are no boundaries must be detected), parsed in blocks of 4 KB / 64 KB / 8 MB"""
+    pkg = load_pkg()
+    rng = np.random.default_rng(5)
+    parts = []
+    for i in range(6000):
+        n = int(rng.integers(20, 300))
+        s = bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+        q = bytearray(rng.integers(35, 74, size=n, dtype=np.uint8).tolist())
+        if i % 3 == 0:
+            q[0] = ord("@")
+        if i % 5 == 0:
+            q[0] = ord("+")
+        zone = (i // 500) % 6
+        if zone == 2 and n > 80:  # multi-line
+            parts.append(b"@ml%d x\n" % i + s[:40] + b"\n" + s[40:] + b"\n+\n" + bytes(q[:40]) + b"\n" + bytes(q[40:]) + b"\n")
+        elif zone == 3:
+            parts.append(b"@cr%d\r\n" % i + s + b"\r\n+\r\n" + bytes(q) + b"\r\n")
+        elif zone == 4:
+            parts.append(b">fa%d some text\n" % i + s + b"\n")
+        else:
+            parts.append(b"@r%d c=%d\n" % (i, i) + s + b"\n+\n" + bytes(q) + b"\n")
+        if i == 2750:
+            parts.append(b"@broken\nACGTACGT\n+\nIII\n")
+    path = os.path.join(str(tmp_path), "mixed.fq")
+    with open(path, "wb") as f:
+        f.write(b"".join(parts))
+    monkeypatch.setenv("GDIET_FASTX_BLOCK", str(block))
+
+    def all_batches(threads, chunk):
+        out = []
+        with pkg.FastxReader(path, threads=threads) as r:
+            while True:
+                b = r.read(chunk, with_qual=True, with_comment=True)
+                if not b and not r.truncated_now:
+                    break
+                out.append((b, r.truncated_now))
+        return out
+
+    for chunk in (3000, 10 ** 7):
+        want = all_batches(1, chunk)
+        assert sum(len(b) for b, _ in want) == 6000
+        assert sum(1 for _, t in want if t) == 1  # the malformed record closes exactly one batch early
+        for threads in (2, 5):
+            assert all_batches(threads, chunk) == want
