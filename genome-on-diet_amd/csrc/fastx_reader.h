@@ -6,12 +6,14 @@
 // of a batch parsed straight into one arena (no allocation per read), plain files read without zlib's extra copy.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <algorithm>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <zlib.h>
@@ -120,10 +122,20 @@ struct GdFastx {
 	bool file_end = false, io_error = false;
 	int n_threads = 1;
 	size_t block_size = (size_t)8 << 20; // per parser thread
-	std::vector<unsigned char> block;    // [0, fill): unparsed tail of the previous block + fresh bytes
+	// The block being parsed is bp[0, fill) = the unparsed tail of the previous block + fresh bytes; bp points into block.  While it
+	// is parsed, an I/O thread reads the next stretch of the file into `other` (behind room for the tail, which is copied in front
+	// of it once known), so reading and parsing overlap and no block is ever moved.
+	std::vector<unsigned char> block, other;
+	const unsigned char *bp = nullptr;
 	size_t fill = 0;
+	std::thread io;
+	bool io_pending = false;
+	size_t io_base = 0, io_tail = 0, io_got = 0; // other[io_base - io_tail, io_base) = tail, other[io_base, io_base + io_got) = fresh
+	bool io_eof = false, io_err = false;
 	std::deque<std::unique_ptr<GdFastxChunk>> ready; // parsed, not yet (completely) handed out
 	std::vector<std::unique_ptr<GdFastxChunk>> lent; // handed out by the last call: alive until the next one
+	std::vector<std::unique_ptr<GdFastxChunk>> pool; // used chunks, kept for their memory (fresh pages cost several times the parsing)
+	std::mutex pool_mu;
 	bool with_qual = true, with_comment = false, flags_set = false;
 	std::vector<const char *> v_name, v_comment, v_seq, v_qual;
 	std::vector<int32_t> v_len;
@@ -133,22 +145,44 @@ struct GdFastx {
 		const size_t l = strlen(s);
 		return l >= 3 && s[l - 1] >= '0' && s[l - 1] <= '9' && s[l - 2] == '/' ? l - 2 : l;
 	}
-	bool read_more(size_t want)
+	// read up to `want` bytes to dst; sets eof / err
+	void io_read(unsigned char *dst, size_t want, size_t *got_, bool *eof_, bool *err_)
 	{
-		if (file_end) return false;
-		if (block.size() < fill + want) block.resize(fill + want);
 		size_t got = 0;
+		*eof_ = *err_ = false;
 		while (got < want) {
 			long n;
 			if (fd >= 0) {
-				do n = (long)::read(fd, block.data() + fill + got, want - got); while (n < 0 && errno == EINTR);
-			} else n = gzread(fp, block.data() + fill + got, (unsigned)std::min<size_t>(want - got, (size_t)1 << 30));
-			if (n < 0) { io_error = true, file_end = true; break; }
-			if (n == 0) { file_end = true; break; }
+				do n = (long)::read(fd, dst + got, want - got); while (n < 0 && errno == EINTR);
+			} else n = gzread(fp, dst + got, (unsigned)std::min<size_t>(want - got, (size_t)1 << 30));
+			if (n < 0) { *err_ = true, *eof_ = true; break; }
+			if (n == 0) { *eof_ = true; break; }
 			got += (size_t)n;
 		}
-		fill += got;
-		return got > 0;
+		*got_ = got;
+	}
+	// start reading the next `want` bytes into `other`, in front of which the tail bp[pos, fill) of the current block is placed
+	void prefetch(size_t pos, size_t want)
+	{
+		const size_t t = fill - pos;
+		io_tail = t, io_base = (t + 4095) & ~(size_t)4095;
+		if (other.size() < io_base + want) other.resize(io_base + want);
+		if (t) memcpy(other.data() + io_base - t, bp + pos, t);
+		if (file_end) { io_got = 0, io_eof = true, io_err = false, io_pending = true; return; } // nothing more to read: only the tail moves
+		unsigned char *dst = other.data() + io_base;
+		io = std::thread([this, dst, want] { io_read(dst, want, &io_got, &io_eof, &io_err); });
+		io_pending = true;
+	}
+	// make the prefetched stretch the current block
+	void take_prefetched()
+	{
+		if (io.joinable()) io.join();
+		io_pending = false;
+		block.swap(other);
+		bp = block.data() + io_base - io_tail;
+		fill = io_tail + io_got;
+		if (io_eof) file_end = true;
+		if (io_err) io_error = true;
 	}
 	// Parse block[from, fill) sequentially into C, never starting a record at or after `stop` (the next parser's first record, or
 	// `fill`).  Returns where the next record would start: exactly `stop` when the stretch ends on the seam (or the range is
@@ -157,13 +191,13 @@ struct GdFastx {
 	size_t parse_range(GdFastxChunk &C, size_t from, size_t stop, bool last_of_file) const
 	{
 		GdFastxParser P;
-		P.b = block.data(), P.end = fill;
+		P.b = bp, P.end = fill;
 		size_t pos = from;
 		P.arena.swap(C.arena);
 		for (;;) {
 			// the header scan of kseq_read: the next '>' or '@', wherever it stands
 			size_t h = pos;
-			while (h < fill && block[h] != '>' && block[h] != '@') ++h;
+			while (h < fill && bp[h] != '>' && bp[h] != '@') ++h;
 			if (h >= stop) { pos = h >= fill ? fill : h; break; } // (h == stop: the seam; h > stop: not a boundary, the caller sees it)
 			P.begin = h, P.eof = false, P.last_char = 0;
 			int64_t o[4];
@@ -182,7 +216,7 @@ struct GdFastx {
 	// a position in (from, fill) that looks like the first byte of a four-line FASTQ record
 	size_t find_seam(size_t from) const
 	{
-		const unsigned char *b = block.data();
+		const unsigned char *b = bp;
 		for (size_t p = from; p < fill;) {
 			const void *nl = memchr(b + p, '\n', fill - p);
 			if (!nl) return fill;
@@ -207,12 +241,29 @@ struct GdFastx {
 		}
 		return fill;
 	}
+	std::unique_ptr<GdFastxChunk> fresh_chunk()
+	{
+		std::unique_ptr<GdFastxChunk> c;
+		{
+			std::lock_guard<std::mutex> lk(pool_mu);
+			if (!pool.empty()) c = std::move(pool.back()), pool.pop_back();
+		}
+		if (!c) c.reset(new GdFastxChunk());
+		c->arena.clear(), c->off.clear(), c->len.clear(), c->err.clear(), c->err_first = false, c->next = 0;
+		return c;
+	}
 	// read and parse one more block; false when the input is exhausted
 	bool parse_more()
 	{
 		size_t want = block_size * (size_t)n_threads;
 		for (;;) {
-			const bool got = read_more(want);
+			if (!io_pending) { // the very first block: nothing was read ahead
+				if (file_end) return false;
+				if (block.size() < want) block.resize(want);
+				bool e, r;
+				io_read(block.data(), want, &fill, &e, &r);
+				bp = block.data(), file_end = e, io_error = r;
+			} else take_prefetched();
 			if (fill == 0) return false;
 			// split points: record starts verified by look-ahead; whether they ARE boundaries of the sequential grammar is checked
 			// afterwards (every stretch must end exactly where the next one began) -- if not, the rest is parsed again in sequence
@@ -227,7 +278,7 @@ struct GdFastx {
 			std::vector<std::unique_ptr<GdFastxChunk>> parts(nr);
 			std::vector<size_t> endpos(nr, 0);
 			auto work = [&](size_t k) {
-				parts[k].reset(new GdFastxChunk());
+				parts[k] = fresh_chunk();
 				endpos[k] = parse_range(*parts[k], cut[k], k + 1 < nr ? cut[k + 1] : fill, file_end);
 			};
 			if (nr > 1) {
@@ -239,26 +290,28 @@ struct GdFastx {
 			size_t good = 1; // stretches [0, good) are what a sequential parse would have produced
 			while (good < nr && endpos[good - 1] == cut[good]) ++good;
 			size_t pos = endpos[good - 1];
+			if (getenv("GDIET_FASTX_TRACE")) fprintf(stderr, "[fastx] block %zu bytes, %zu stretches, %zu good, file_end %d\n", fill, nr, good, (int)file_end);
 			if (good < nr) { // a seam was no boundary: everything after the last good stretch again, in sequence
 				parts.resize(good + 1);
-				parts[good].reset(new GdFastxChunk());
+				parts[good] = fresh_chunk();
 				pos = parse_range(*parts[good], endpos[good - 1], fill, file_end);
 			}
 			size_t n_rec = 0;
-			for (auto &c : parts) if (c) { n_rec += c->len.size() + (c->err_first ? 1 : 0); if (!c->len.empty() || c->err_first) ready.push_back(std::move(c)); }
-			// keep the unparsed tail (a record cut off by the block end) for the next round
-			memmove(block.data(), block.data() + pos, fill - pos);
-			fill -= pos;
+			for (auto &c : parts) if (c) { n_rec += c->len.size() + (c->err_first ? 1 : 0); if (!c->len.empty() || c->err_first) ready.push_back(std::move(c)); else if (pool.size() < 64) pool.push_back(std::move(c)); }
+			// the unparsed tail (a record cut off by the block end) goes in front of the next stretch of the file, which is read while
+			// the caller works on what was parsed
+			if (file_end && pos >= fill) { fill = 0, io_pending = false; return n_rec > 0; }
+			if (!n_rec && !file_end) want *= 2; // a record longer than the block: read on, in bigger steps
+			if (!n_rec && file_end) { fill = 0, io_pending = false; return false; } // (only separators / a malformed rest were left)
+			prefetch(pos, want);
 			if (n_rec) return true;
-			if (file_end) { fill = 0; return false; } // (only separators / a malformed rest were left)
-			if (!got && fill == 0) return false;
-			want *= 2; // a record longer than the block: read on
 		}
 	}
 	// mm_bseq_read3 (LR/bseq.c:80-121); returns the number of reads of the batch (0 at the end of the file), < 0 on a read error
 	int read_batch(int64_t chunk_size, bool wq, bool wc, bool frag_mode, bool *parse_error)
 	{
 		if (!flags_set) with_qual = wq, with_comment = wc, flags_set = true; // (the flags of the first call hold for the whole file)
+		for (auto &c : lent) if (pool.size() < 64) pool.push_back(std::move(c));
 		lent.clear();
 		v_name.clear(), v_comment.clear(), v_seq.clear(), v_qual.clear(), v_len.clear();
 		if (parse_error) *parse_error = false;
@@ -322,6 +375,7 @@ static inline GdFastx *gd_fastx_open(const char *path)
 static inline void gd_fastx_close(GdFastx *fx)
 {
 	if (!fx) return;
+	if (fx->io.joinable()) fx->io.join();
 	if (fx->fp) gzclose(fx->fp);
 	if (fx->fd >= 0) ::close(fx->fd);
 	delete fx;
