@@ -225,3 +225,26 @@ def test_parallel_parse_equals_sequential_parse(tmp_path, block, monkeypatch):
         assert sum(1 for _, t in want if t) == 1  # the malformed record closes exactly one batch early
         for threads in (2, 5):
             assert all_batches(threads, chunk) == want
+
+
+def test_reader_threads_under_thread_sanitizer(tmp_path):
+    """the parser threads and the read-ahead thread of csrc/fastx_reader.h, built alone with -fsanitize=thread"""
+    exe = str(tmp_path / "fastx_test")
+    subprocess.check_call(["g++", "-fsanitize=thread", "-O1", "-g", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "genome-on-diet_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "emul", "fastx_test.cpp"), "-o", exe, "-lz"])
+    rng = np.random.default_rng(9)
+    path = os.path.join(str(tmp_path), "t.fq")
+    with open(path, "wb") as f:
+        for i in range(3000):
+            n = int(rng.integers(20, 200))
+            s = bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+            q = bytearray(rng.integers(35, 74, size=n, dtype=np.uint8).tolist())
+            if i % 4 == 0:
+                q[0] = ord("@")
+            if 1000 <= i < 1300 and n > 60:
+                f.write(b"@m%d\n" % i + s[:30] + b"\n" + s[30:] + b"\n+\n" + bytes(q[:30]) + b"\n" + bytes(q[30:]) + b"\n")
+            else:
+                f.write(b"@r%d k\n" % i + s + b"\n+\n" + bytes(q) + b"\n")
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok 3000 records" in r.stdout and "ThreadSanitizer" not in r.stderr
