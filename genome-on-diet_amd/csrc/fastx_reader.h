@@ -132,9 +132,9 @@ struct GdFastx {
 	bool io_pending = false;
 	size_t io_base = 0, io_tail = 0, io_got = 0; // other[io_base - io_tail, io_base) = tail, other[io_base, io_base + io_got) = fresh
 	bool io_eof = false, io_err = false;
-	std::deque<std::unique_ptr<GdFastxChunk>> ready; // parsed, not yet (completely) handed out
-	std::vector<std::unique_ptr<GdFastxChunk>> lent; // handed out by the last call: alive until the next one
-	std::vector<std::unique_ptr<GdFastxChunk>> pool; // used chunks, kept for their memory (fresh pages cost several times the parsing)
+	std::deque<std::shared_ptr<GdFastxChunk>> ready; // parsed, not yet (completely) handed out
+	std::vector<std::shared_ptr<GdFastxChunk>> lent; // every chunk the last batch points into: alive until the next call (or, detached, longer)
+	std::vector<std::shared_ptr<GdFastxChunk>> pool; // used chunks, kept for their memory (fresh pages cost several times the parsing)
 	std::mutex pool_mu;
 	bool with_qual = true, with_comment = false, flags_set = false;
 	std::vector<const char *> v_name, v_comment, v_seq, v_qual;
@@ -241,9 +241,9 @@ struct GdFastx {
 		}
 		return fill;
 	}
-	std::unique_ptr<GdFastxChunk> fresh_chunk()
+	std::shared_ptr<GdFastxChunk> fresh_chunk()
 	{
-		std::unique_ptr<GdFastxChunk> c;
+		std::shared_ptr<GdFastxChunk> c;
 		{
 			std::lock_guard<std::mutex> lk(pool_mu);
 			if (!pool.empty()) c = std::move(pool.back()), pool.pop_back();
@@ -275,7 +275,7 @@ struct GdFastx {
 					cut.push_back(c);
 				}
 			const size_t nr = cut.size();
-			std::vector<std::unique_ptr<GdFastxChunk>> parts(nr);
+			std::vector<std::shared_ptr<GdFastxChunk>> parts(nr);
 			std::vector<size_t> endpos(nr, 0);
 			auto work = [&](size_t k) {
 				parts[k] = fresh_chunk();
@@ -311,14 +311,14 @@ struct GdFastx {
 	int read_batch(int64_t chunk_size, bool wq, bool wc, bool frag_mode, bool *parse_error)
 	{
 		if (!flags_set) with_qual = wq, with_comment = wc, flags_set = true; // (the flags of the first call hold for the whole file)
-		for (auto &c : lent) if (pool.size() < 64) pool.push_back(std::move(c));
+		for (auto &c : lent) if (c.use_count() == 1 && pool.size() < 64) pool.push_back(std::move(c)); // (not in `ready` any more, not detached)
 		lent.clear();
 		v_name.clear(), v_comment.clear(), v_seq.clear(), v_qual.clear(), v_len.clear();
 		if (parse_error) *parse_error = false;
 		int64_t size = 0;
 		bool closing = false; // the batch is full: only mates of its last read may still join (fragment mode)
 		for (;;) {
-			while (!ready.empty() && ready.front()->next >= ready.front()->len.size() && !ready.front()->err_first) lent.push_back(std::move(ready.front())), ready.pop_front();
+			while (!ready.empty() && ready.front()->next >= ready.front()->len.size() && !ready.front()->err_first) ready.pop_front();
 			if (ready.empty() && !parse_more()) break;
 			if (ready.empty()) continue;
 			GdFastxChunk &C = *ready.front();
@@ -331,6 +331,7 @@ struct GdFastx {
 				const size_t l1 = qname_len(nm), l2 = qname_len(prev);
 				if (!(l1 == l2 && strncmp(nm, prev, l1) == 0)) break;
 			}
+			if (lent.empty() || lent.back().get() != &C) lent.push_back(ready.front());
 			v_name.push_back(nm);
 			v_comment.push_back(C.off[4 * i + 1] < 0 ? nullptr : C.arena.data() + C.off[4 * i + 1]);
 			v_seq.push_back(C.arena.data() + C.off[4 * i + 2]);
@@ -349,6 +350,20 @@ struct GdFastx {
 		return (int)v_len.size();
 	}
 };
+
+// a batch taken out of the reader (several mini-batches in flight): owns the pointer arrays and keeps the chunks alive
+struct GdFastxBatch {
+	std::vector<std::shared_ptr<GdFastxChunk>> chunks;
+	std::vector<const char *> v_name, v_comment, v_seq, v_qual;
+	std::vector<int32_t> v_len;
+};
+static inline GdFastxBatch *gd_fastx_detach(GdFastx *fx)
+{
+	GdFastxBatch *b = new GdFastxBatch();
+	b->chunks = fx->lent; // (shared: the reader may still hand out the rest of the last chunk)
+	b->v_name.swap(fx->v_name), b->v_comment.swap(fx->v_comment), b->v_seq.swap(fx->v_seq), b->v_qual.swap(fx->v_qual), b->v_len.swap(fx->v_len);
+	return b;
+}
 
 static inline GdFastx *gd_fastx_open(const char *path)
 {

@@ -741,6 +741,19 @@ extern "C" int gdiet_hip_fastx_read(gdiet_fastx *fx, int64_t chunk_size, int wit
 	return bad ? GDIET_W_TRUNCATED : GDIET_OK;
 }
 
+struct gdiet_fastx_batch { GdFastxBatch *b; };
+extern "C" gdiet_fastx_batch *gdiet_hip_fastx_detach(gdiet_fastx *fx)
+{
+	if (!fx || !fx->r) return nullptr;
+	return new gdiet_fastx_batch{gd_fastx_detach(fx->r)};
+}
+extern "C" void gdiet_hip_fastx_batch_free(gdiet_fastx_batch *b)
+{
+	if (!b) return;
+	delete b->b;
+	delete b;
+}
+
 extern "C" int gdiet_hip_fastx_set_threads(gdiet_fastx *fx, int n)
 {
 	if (!fx || !fx->r || n < 1 || n > 64) return GDIET_E_PARAM;

@@ -43,6 +43,31 @@ class FastxReader:
             out.append((names[i], s, quals[i], comments[i]))
         return out
 
+    def read_raw(self, chunk_size, with_qual=True, with_comment=False, frag_mode=False, detach=False):
+        """next mini-batch as C arrays: (n, names, comments, seqs, quals, lens, token).  With detach=True the arrays stay valid until
+        release(token) (several mini-batches in flight); otherwise until the next read."""
+        cpp = C.POINTER(C.c_char_p)
+        n = C.c_int32()
+        names, comments, seqs, quals, lens = cpp(), cpp(), cpp(), cpp(), C.POINTER(C.c_int32)()
+        rc = self.lib.gdiet_hip_fastx_read(self._h, chunk_size, int(with_qual), int(with_comment), int(frag_mode), C.byref(n), C.byref(names),
+                                           C.byref(comments), C.byref(seqs), C.byref(quals), C.byref(lens))
+        if rc < 0:
+            raise GdietError("read error")
+        self.truncated_now = rc == W_TRUNCATED
+        self.truncated = self.truncated or self.truncated_now
+        token = None
+        if detach and n.value:
+            self.lib.gdiet_hip_fastx_detach.restype = C.c_void_p
+            self.lib.gdiet_hip_fastx_detach.argtypes = [C.c_void_p]
+            token = C.c_void_p(self.lib.gdiet_hip_fastx_detach(self._h))
+        return n.value, names, comments, seqs, quals, lens, token
+
+    def release(self, token):
+        if token:
+            self.lib.gdiet_hip_fastx_batch_free.argtypes = [C.c_void_p]
+            self.lib.gdiet_hip_fastx_batch_free.restype = None
+            self.lib.gdiet_hip_fastx_batch_free(token)
+
     def close(self):
         if self._h:
             self.lib.gdiet_hip_fastx_close(self._h)

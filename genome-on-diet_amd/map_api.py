@@ -232,6 +232,24 @@ class Mapper:
         self.ctx._check(self.lib.gdiet_hip_batch_upload(self.ctx._h, C.byref(h), n, arr, lens.ctypes.data_as(C.POINTER(C.c_int32))))
         return (h, n)
 
+    def upload_raw(self, n, seqs, lens):
+        """gdiet_hip_batch_upload on C arrays as they are (e.g. the ones gdiet_hip_fastx_read returned): no Python object per read"""
+        h = C.c_void_p()
+        self.ctx._check(self.lib.gdiet_hip_batch_upload(self.ctx._h, C.byref(h), n, C.cast(seqs, C.POINTER(C.c_char_p)), lens))
+        return (h, n)
+
+    def sam_batch_raw(self, res, n, names, seqs, quals, lens):
+        """gdiet_hip_sam_batch on C arrays; returns bytes"""
+        out = C.c_void_p()
+        cpp = C.POINTER(C.c_char_p)
+        m = self.lib.gdiet_hip_sam_batch(self.ctx._h, self._idx, n, C.cast(names, cpp), C.cast(seqs, cpp), C.cast(quals, cpp), lens, res.n_regs, res.regs,
+                                         self.opt.flag, C.byref(out))
+        try:
+            return C.string_at(out.value, m) if out.value else b""
+        finally:
+            if out.value:
+                C.CDLL(None).free(C.c_void_p(out.value))
+
     def map_uploaded(self, batch):
         h, n = batch
         n_regs = (C.c_int32 * n)()

@@ -264,6 +264,11 @@ int gdiet_hip_fastx_open(gdiet_fastx **fx, const char *path);
 int gdiet_hip_fastx_read(gdiet_fastx *fx, int64_t chunk_size, int with_qual, int with_comment, int frag_mode, int32_t *n_reads,
                          const char *const **names, const char *const **comments, const char *const **seqs,
                          const char *const **quals, const int32_t **lens);
+/* Several mini-batches in flight: take the batch the last gdiet_hip_fastx_read returned out of the reader.  Its arrays and strings
+ * (the pointers that call handed out) then stay valid until gdiet_hip_fastx_batch_free, whatever is read in the meantime. */
+typedef struct gdiet_fastx_batch gdiet_fastx_batch;
+gdiet_fastx_batch *gdiet_hip_fastx_detach(gdiet_fastx *fx);
+void gdiet_hip_fastx_batch_free(gdiet_fastx_batch *b);
 /* parser threads (default 1).  Blocks of the file are cut at places that look like the start of a four-line FASTQ record and the
  * stretches parsed side by side; a stretch that does not end exactly where the next one began proves the cut wrong, and the rest of
  * the block is parsed again in sequence -- so the records are those of the sequential grammar whatever the input looks like. */

@@ -294,3 +294,23 @@ def test_file_to_sam_through_the_library(gpu_ctx, pkg, kind):
             assert "".join(out) == "".join(l + "\n" for l in golden_sam(kind))
     finally:
         m.close()
+
+
+def test_file_to_sam_with_batches_in_flight(gpu_ctx, pkg, tmp_path):
+    """tools/map_file.py's route: detached reader batches (C arrays, no Python object per read), three mini-batches in flight, SAM
+    written batch by batch -- the file is the golden SAM body"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import map_file
+    from fixture_io import SR
+    names, seqs = read_fasta(os.path.join(SR, "ref.fa.gz"))
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset="sr")
+    try:
+        for chunk, threads in ((30000, 1), (45000, 3)):
+            out = str(tmp_path / ("out%d.sam" % chunk))
+            with open(out, "wb") as f:
+                n, _ = map_file.map_file(pkg, m, os.path.join(SR, "sr.fq.gz"), f, chunk, 3, threads)
+            assert n == 2000
+            assert open(out).read() == "".join(l + "\n" for l in golden_sam("sr"))
+    finally:
+        m.close()
