@@ -68,6 +68,7 @@ struct gdiet_ctx {
 	bool shared_sticky = false;        // (lane) a recent batch did not fit a private arena
 	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool async_busy[4] = {false, false, false, false};
+	std::mutex async_mu;               // guards the ticket bookkeeping of submit / wait
 	int async_next = 0, async_depth = 2;
 	bool last_was_async = false;       // gdiet_hip_last_kernel_ms then reports the lane's events, copied at gdiet_hip_map_wait
 	float async_dp_ms = 0, async_bt_ms = 0;

@@ -721,7 +721,15 @@ static inline void gd_sr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 }
 
 // ---- SAM record, LR/format.c:412-599 for the single-segment case the path produces ------------------------------------------
-static inline void gd_fmt_int(std::string &s, long long v) { char b[32]; snprintf(b, sizeof b, "%lld", v); s += b; }
+static inline void gd_fmt_int(std::string &s, long long v) // decimal, as "%lld" (hand-rolled: a SAM record holds a dozen of them)
+{
+	char b[24];
+	int n = 24;
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	do b[--n] = (char)('0' + u % 10), u /= 10; while (u);
+	if (v < 0) b[--n] = '-';
+	s.append(b + n, (size_t)(24 - n));
+}
 
 static inline void gd_write_sam(std::string &s, const GdRefView &R, const char *qname, const char *seq, const char *qual, int l_seq,
                                 const std::vector<GdReg> &regs, int reg_idx, int64_t opt_flag)
@@ -739,13 +747,16 @@ static inline void gd_write_sam(std::string &s, const GdRefView &R, const char *
 	s += '\t'; gd_fmt_int(s, flag);
 	auto put_seq = [&](const char *p, int l, int rev, int comp) {
 		if (!rev) { s.append(p, (size_t)l); return; }
+		const size_t at = s.size();
+		s.resize(at + (size_t)l);
+		char *d = &s[at];
 		for (int i = 0; i < l; ++i) {
 			int c = (unsigned char)p[l - 1 - i];
 			if (comp && c < 128) {
 				if (c >= 'A' && c <= 'Z') c = comp_tab[c - 'A'];
 				else if (c >= 'a' && c <= 'z') c = comp_tab[c - 'a'] + 32;
 			}
-			s += (char)c;
+			d[i] = (char)c;
 		}
 	};
 	if (!r) {

@@ -213,10 +213,12 @@ extern "C" int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **out, in
 		uint8_t *d = b->enc.data() + b->roff[i];
 		for (int j = 0; j < lens[i]; ++j) d[j] = gd_nt4((unsigned char)seqs[i][j]);
 	});
-	hipError_t e = hipMalloc(&b->d_reads, b->enc.size());
-	if (e == hipSuccess) e = hipMalloc(&b->d_roff, sizeof(int64_t) * (n + 1));
-	if (e == hipSuccess) e = hipMemcpy(b->d_reads, b->enc.data(), b->enc.size(), hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(b->d_roff, b->roff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice);
+	// stream-ordered allocation: a plain hipMalloc / hipFree per mini-batch synchronises the whole device, i.e. every batch in flight
+	hipError_t e = hipMallocAsync(&b->d_reads, b->enc.size(), ctx->stream);
+	if (e == hipSuccess) e = hipMallocAsync(&b->d_roff, sizeof(int64_t) * (n + 1), ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(b->d_reads, b->enc.data(), b->enc.size(), hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(b->d_roff, b->roff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	if (e != hipSuccess) { ctx->err = std::string("batch upload: ") + hipGetErrorString(e); delete b; return GDIET_E_HIP; }
 	*out = b;
 	return GDIET_OK;
@@ -226,8 +228,13 @@ extern "C" void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *b)
 {
 	if (!b) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
-	if (b->d_reads) (void)hipFree(b->d_reads);
-	if (b->d_roff) (void)hipFree(b->d_roff);
+	if (ctx) {
+		if (b->d_reads) (void)hipFreeAsync(b->d_reads, ctx->stream);
+		if (b->d_roff) (void)hipFreeAsync(b->d_roff, ctx->stream);
+	} else {
+		if (b->d_reads) (void)hipFree(b->d_reads);
+		if (b->d_roff) (void)hipFree(b->d_roff);
+	}
 	delete b;
 }
 
@@ -737,6 +744,7 @@ extern "C" int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *ix, const
 {
 	if (!ctx || !ix || !copt || !B || !n_regs || !regs || !out) return GDIET_E_PARAM;
 	(void)hipSetDevice(ctx->device);
+	std::lock_guard<std::mutex> guard(ctx->async_mu); // (submit and wait may come from different threads of the caller's pipeline)
 	gdiet_map_ticket *t = new gdiet_map_ticket();
 	gd_opt_from_c(copt, ix, t->O);
 	int rc = gd_check_opt(ctx, t->O);
@@ -770,6 +778,7 @@ extern "C" int gdiet_hip_map_wait(gdiet_ctx *ctx, gdiet_map_ticket *t)
 {
 	if (!ctx || !t) return GDIET_E_PARAM;
 	if (t->th.joinable()) t->th.join();
+	std::lock_guard<std::mutex> guard(ctx->async_mu);
 	gdiet_ctx *c = ctx->async_lane[t->lane];
 	const int rc = t->rc;
 	if (rc) ctx->err = c->err;
@@ -822,36 +831,48 @@ extern "C" size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *ix, int
 {
 	if (!ctx || !ix || n_reads < 0 || !qnames || !seqs || !lens || !n_regs || !regs || !out) return 0;
 	*out = nullptr;
-	std::vector<std::string> rec((size_t)n_reads);
-	gd_parallel_for(ctx, ctx->host_threads, n_reads, [&](int i) {
-		const int nr = n_regs[i];
-		std::vector<GdReg> v(nr > 0 ? nr : 0);
-		for (int j = 0; j < nr; ++j) {
-			const gdiet_reg_t &r = regs[i][j];
-			GdReg &g = v[j];
-			g.id = r.id, g.cnt = r.cnt, g.rid = r.rid, g.score = r.score, g.qs = r.qs, g.qe = r.qe, g.rs = r.rs, g.re = r.re, g.parent = r.parent, g.subsc = r.subsc;
-			g.mlen = r.mlen, g.blen = r.blen, g.mapq = r.mapq, g.rev = r.rev, g.sam_pri = r.sam_pri, g.dp_score = r.dp_score, g.dp_max = r.dp_max, g.n_ambi = r.n_ambi;
-			g.has_p = true, g.cigar.assign(r.cigar, r.cigar + r.n_cigar);
-		}
-		std::string &s = rec[i], one;
-		const char *q = quals ? quals[i] : nullptr;
-		if (nr <= 0) {
-			gd_write_sam(one, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, -1, opt_flag);
-			s += one, s += '\n';
-		} else
+	// formatted in chunks of 512 reads (one string per chunk, not per read: a short-read batch has a quarter of a million reads, and
+	// every string made by a worker is released by this thread), then copied side by side into the output
+	const int CH = 512, n_ch = (n_reads + CH - 1) / CH;
+	std::vector<std::string> rec((size_t)n_ch);
+	gd_parallel_for(ctx, ctx->host_threads, n_ch, [&](int c) {
+		static thread_local std::vector<GdReg> v; // per-thread scratch, reused from read to read
+		static thread_local std::string one;
+		std::string &s = rec[c];
+		const int i1 = std::min(n_reads, (c + 1) * CH);
+		size_t guess = 0;
+		for (int i = c * CH; i < i1; ++i) guess += 2 * (size_t)lens[i] + 160;
+		s.reserve(guess);
+		for (int i = c * CH; i < i1; ++i) {
+			const int nr = n_regs[i];
+			v.resize(nr > 0 ? nr : 0);
 			for (int j = 0; j < nr; ++j) {
-				if ((opt_flag & GD_F_NO_PRINT_2ND) && v[j].id != v[j].parent) continue;
-				one.clear();
-				gd_write_sam(one, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, j, opt_flag);
-				s += one, s += '\n';
+				const gdiet_reg_t &r = regs[i][j];
+				GdReg &g = v[j];
+				g.id = r.id, g.cnt = r.cnt, g.rid = r.rid, g.score = r.score, g.qs = r.qs, g.qe = r.qe, g.rs = r.rs, g.re = r.re, g.parent = r.parent, g.subsc = r.subsc;
+				g.mlen = r.mlen, g.blen = r.blen, g.mapq = r.mapq, g.rev = r.rev, g.sam_pri = r.sam_pri, g.dp_score = r.dp_score, g.dp_max = r.dp_max, g.n_ambi = r.n_ambi;
+				g.has_p = true, g.cigar.assign(r.cigar, r.cigar + r.n_cigar);
 			}
+			const char *q = quals ? quals[i] : nullptr;
+			if (nr <= 0) {
+				one.clear();
+				gd_write_sam(one, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, -1, opt_flag);
+				s += one, s += '\n';
+			} else
+				for (int j = 0; j < nr; ++j) {
+					if ((opt_flag & GD_F_NO_PRINT_2ND) && v[j].id != v[j].parent) continue;
+					one.clear();
+					gd_write_sam(one, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, j, opt_flag);
+					s += one, s += '\n';
+				}
+		}
 	});
-	size_t tot = 0;
-	for (auto &r : rec) tot += r.size();
+	std::vector<size_t> at((size_t)n_ch + 1, 0);
+	for (int c = 0; c < n_ch; ++c) at[c + 1] = at[c] + rec[c].size();
+	const size_t tot = at[n_ch];
 	char *buf = (char *)malloc(tot + 1);
 	if (!buf) return 0;
-	size_t o = 0;
-	for (auto &r : rec) memcpy(buf + o, r.data(), r.size()), o += r.size();
+	gd_parallel_for(ctx, ctx->host_threads, n_ch, [&](int c) { memcpy(buf + at[c], rec[c].data(), rec[c].size()); });
 	buf[tot] = 0;
 	*out = buf;
 	return tot;

@@ -238,14 +238,20 @@ class Mapper:
         self.ctx._check(self.lib.gdiet_hip_batch_upload(self.ctx._h, C.byref(h), n, C.cast(seqs, C.POINTER(C.c_char_p)), lens))
         return (h, n)
 
-    def sam_batch_raw(self, res, n, names, seqs, quals, lens):
-        """gdiet_hip_sam_batch on C arrays; returns bytes"""
+    def sam_batch_raw(self, res, n, names, seqs, quals, lens, sink=None):
+        """gdiet_hip_sam_batch on C arrays.  With sink (a binary file object) the text is written from the C buffer without a copy and
+        its length returned; otherwise bytes are returned."""
         out = C.c_void_p()
         cpp = C.POINTER(C.c_char_p)
         m = self.lib.gdiet_hip_sam_batch(self.ctx._h, self._idx, n, C.cast(names, cpp), C.cast(seqs, cpp), C.cast(quals, cpp), lens, res.n_regs, res.regs,
                                          self.opt.flag, C.byref(out))
         try:
-            return C.string_at(out.value, m) if out.value else b""
+            if not out.value:
+                return 0 if sink is not None else b""
+            if sink is not None:
+                sink.write(memoryview((C.c_char * m).from_address(out.value)))
+                return m
+            return C.string_at(out.value, m)
         finally:
             if out.value:
                 C.CDLL(None).free(C.c_void_p(out.value))

@@ -20,32 +20,72 @@ from __graft_entry__ import _load_pkg  # noqa: E402
 
 
 def map_file(pkg, mapper, reads_path, out, chunk, inflight, reader_threads):
-    """returns (reads, seconds)"""
+    """returns (reads, seconds).  Three stages on three threads, as the reference's kt_pipeline runs its three steps (LR/map.c:2094-2170):
+    read -> upload + submit -> wait + format + write; the C calls release the interpreter lock, so the stages overlap."""
+    import queue
+    import threading
     fx = pkg.FastxReader(reads_path, threads=reader_threads)
     mapper.set_inflight(inflight)
-    open_q, n_reads = [], 0
+    T = {"read": 0.0, "upload": 0.0, "submit": 0.0, "wait": 0.0, "sam+write": 0.0, "free": 0.0}
+    q_read, q_done = queue.Queue(maxsize=2), queue.Queue()
+    open_tickets = threading.Semaphore(inflight)  # the library takes at most `inflight` tickets: one permit per open ticket
+    errors = []
     t0 = time.perf_counter()
 
-    def finish(item):
-        ticket, token, n, names, seqs, quals, lens, batch = item
-        res = mapper.wait(ticket)
-        out.write(mapper.sam_batch_raw(res, n, names, seqs, quals, lens))
-        del res
-        mapper.free_batch(batch)
-        fx.release(token)
+    def timed(key, f, *a, **k):
+        t = time.perf_counter()
+        r = f(*a, **k)
+        T[key] += time.perf_counter() - t
+        return r
 
+    def reader():
+        try:
+            while True:
+                item = timed("read", fx.read_raw, chunk, detach=True)
+                q_read.put(item)
+                if item[0] == 0:
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            q_read.put((0,) + (None,) * 6)
+
+    def writer():
+        try:
+            while True:
+                item = q_done.get()
+                if item is None:
+                    return
+                ticket, token, n, names, seqs, quals, lens, batch = item
+                res = timed("wait", mapper.wait, ticket)
+                open_tickets.release()
+                timed("sam+write", mapper.sam_batch_raw, res, n, names, seqs, quals, lens, out)
+
+                def drop():
+                    nonlocal res
+                    res = None
+                    mapper.free_batch(batch)
+                    fx.release(token)
+                timed("free", drop)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th_r, th_w = threading.Thread(target=reader), threading.Thread(target=writer)
+    th_r.start(), th_w.start()
+    n_reads = 0
     while True:
-        n, names, comments, seqs, quals, lens, token = fx.read_raw(chunk, detach=True)
+        n, names, comments, seqs, quals, lens, token = q_read.get()
         if n == 0:
             break
         n_reads += n
-        batch = mapper.upload_raw(n, seqs, lens)
-        open_q.append((mapper.submit(batch), token, n, names, seqs, quals, lens, batch))
-        if len(open_q) == inflight:
-            finish(open_q.pop(0))
-    while open_q:
-        finish(open_q.pop(0))
+        batch = timed("upload", mapper.upload_raw, n, seqs, lens)
+        open_tickets.acquire()
+        q_done.put((timed("submit", mapper.submit, batch), token, n, names, seqs, quals, lens, batch))
+    q_done.put(None)
+    th_r.join(), th_w.join()
     fx.close()
+    if errors:
+        raise errors[0]
+    map_file.last_stage_seconds = {k: round(v, 3) for k, v in T.items()}
     return n_reads, time.perf_counter() - t0
 
 
@@ -71,7 +111,7 @@ def main():
     with open(a.out, "wb") as out:
         n, dt = map_file(pkg, m, a.reads, out, chunk, a.inflight, a.reader_threads)
     print(json.dumps({"reads": n, "seconds": round(dt, 3), "reads_per_s": round(n / dt), "index_s": round(t_idx, 2), "mini_batch_bases": chunk,
-                      "inflight": a.inflight, "reader_threads": a.reader_threads, "out": a.out}))
+                      "inflight": a.inflight, "reader_threads": a.reader_threads, "out": a.out, "caller_seconds": map_file.last_stage_seconds}))
     m.close()
     ctx.close()
 
