@@ -69,6 +69,8 @@ struct gdiet_ctx {
 	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool async_busy[4] = {false, false, false, false};
 	std::mutex async_mu;               // guards the ticket bookkeeping of submit / wait
+	std::vector<std::vector<uint8_t>> enc_pool; // host buffers of destroyed read batches, reused by the next uploads
+	std::mutex enc_mu;
 	int async_next = 0, async_depth = 2;
 	bool last_was_async = false;       // gdiet_hip_last_kernel_ms then reports the lane's events, copied at gdiet_hip_map_wait
 	float async_dp_ms = 0, async_bt_ms = 0;

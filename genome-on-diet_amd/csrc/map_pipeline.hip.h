@@ -204,21 +204,35 @@ extern "C" int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **out, in
 {
 	if (!ctx || !out || n < 0 || (n && (!seqs || !lens))) return GDIET_E_PARAM;
 	(void)hipSetDevice(ctx->device);
+	static const bool trace = getenv("GDIET_TRACE_STAGES") != nullptr;
+	double t_[5] = {gd_now(), 0, 0, 0, 0};
 	gdiet_read_batch *b = new gdiet_read_batch();
 	b->n = n;
 	b->roff.assign(n + 1, 0);
 	for (int i = 0; i < n; ++i) b->roff[i + 1] = b->roff[i] + (lens[i] > 0 ? lens[i] : 0);
-	b->enc.resize((size_t)b->roff[n] + 8);
+	// the host copy of the encoded reads lives in a buffer taken from the context's pool (returned by gdiet_hip_batch_destroy): first
+	// touch of fresh memory -- 77 MB per HiFi mini-batch -- cost ten times the encoding itself
+	const size_t enc_len = (size_t)b->roff[n] + 8;
+	{
+		std::lock_guard<std::mutex> lk(ctx->enc_mu);
+		if (!ctx->enc_pool.empty()) b->enc.swap(ctx->enc_pool.back()), ctx->enc_pool.pop_back();
+	}
+	if (b->enc.size() < enc_len) b->enc.resize(enc_len + (enc_len >> 3));
+	t_[1] = gd_now();
 	gd_parallel_for(ctx, ctx->host_threads, n, [&](int i) {
 		uint8_t *d = b->enc.data() + b->roff[i];
 		for (int j = 0; j < lens[i]; ++j) d[j] = gd_nt4((unsigned char)seqs[i][j]);
 	});
+	t_[2] = gd_now();
 	// stream-ordered allocation: a plain hipMalloc / hipFree per mini-batch synchronises the whole device, i.e. every batch in flight
-	hipError_t e = hipMallocAsync(&b->d_reads, b->enc.size(), ctx->stream);
+	hipError_t e = hipMallocAsync(&b->d_reads, enc_len, ctx->stream);
 	if (e == hipSuccess) e = hipMallocAsync(&b->d_roff, sizeof(int64_t) * (n + 1), ctx->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(b->d_reads, b->enc.data(), b->enc.size(), hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(b->d_reads, b->enc.data(), enc_len, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(b->d_roff, b->roff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream);
+	t_[3] = gd_now();
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	t_[4] = gd_now();
+	if (trace) fprintf(stderr, "[gdiet upload, ms] n=%d alloc %.2f encode %.2f enqueue %.2f sync %.2f\n", n, 1e3 * (t_[1] - t_[0]), 1e3 * (t_[2] - t_[1]), 1e3 * (t_[3] - t_[2]), 1e3 * (t_[4] - t_[3]));
 	if (e != hipSuccess) { ctx->err = std::string("batch upload: ") + hipGetErrorString(e); delete b; return GDIET_E_HIP; }
 	*out = b;
 	return GDIET_OK;
@@ -229,6 +243,10 @@ extern "C" void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *b)
 	if (!b) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
 	if (ctx) {
+		{
+			std::lock_guard<std::mutex> lk(ctx->enc_mu);
+			if (ctx->enc_pool.size() < 6) ctx->enc_pool.push_back(std::move(b->enc));
+		}
 		if (b->d_reads) (void)hipFreeAsync(b->d_reads, ctx->stream);
 		if (b->d_roff) (void)hipFreeAsync(b->d_roff, ctx->stream);
 	} else {

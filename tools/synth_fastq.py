@@ -1,5 +1,5 @@
 """write a synthetic reference (FASTA) and short reads drawn from it (four-line FASTQ) for tools/map_file.py:
-    python tools/synth_fastq.py <dir> [ref_mbp=100] [n_reads=4000000]"""
+    python tools/synth_fastq.py <dir> [ref_mbp=100] [n_reads=4000000] [sr|hifi]"""
 import os
 import sys
 
@@ -20,6 +20,15 @@ def main():
     with open(os.path.join(d, "ref.fa"), "wb") as f:
         for nm, c in zip(names, contigs):
             f.write(b">" + nm.encode() + b"\n" + c.tobytes() + b"\n")
+    kind = sys.argv[4] if len(sys.argv) > 4 else "sr"
+    if kind == "hifi":
+        base = min(n, 20480)
+        reads = [s for _, s in bench.synth_hifi_reads(np.random.default_rng(5), contigs, base)]
+        with open(os.path.join(d, "reads.fq"), "wb") as f:
+            for rep in range(max(1, n // base)):
+                for i, s in enumerate(reads):
+                    f.write(b"@h%d_%d\n" % (rep, i) + s + b"\n+\n" + b"I" * len(s) + b"\n")
+        return
     base = min(n, 500_000)
     reads = synth_reads(np.random.default_rng(7), contigs, base, "sr")
     q = b"I" * 200
