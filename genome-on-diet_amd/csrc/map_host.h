@@ -554,7 +554,7 @@ struct GdDpResult { int32_t score; const uint32_t *cigar; int32_t n_cigar; };
 
 // enc_for / enc_rev: the read encoded 0-4 on the forward strand / reverse-complemented (LR/map.c:1622-1643)
 static inline void gd_lr_finish(std::vector<GdCand> &C, const std::vector<GdDpResult> &dp, const GdMapOpt &O, const GdRefView &R,
-                                uint32_t qlen_sum, const uint8_t *enc_for, const uint8_t *enc_rev, std::vector<GdReg> &out)
+                                uint32_t qlen_sum, const uint8_t *enc_for, const uint8_t *enc_rev, std::vector<GdReg> &out, FILE *trace = nullptr)
 {
 	out.clear();
 	const unsigned n = (unsigned)C.size();
@@ -582,6 +582,9 @@ static inline void gd_lr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 	for (unsigned i = 0; i < n; i++) { // :1856-1874
 		while (C[i].valid && C[i].next >= 0 && C[C[i].next].valid) {
 			GdCand &nx = C[C[i].next];
+			if (trace) // the reference's --print-seeds lines, :1858-1863
+				fprintf(trace, "CONQ[%u, %u] || [%u, %u]\nCONT [%u, %u] || [%u, %u]\n", (unsigned)C[i].r.qs, (unsigned)C[i].r.qe, (unsigned)nx.r.qs, (unsigned)nx.r.qe,
+				        (unsigned)C[i].r.rs, (unsigned)C[i].r.re, (unsigned)nx.r.rs, (unsigned)nx.r.re);
 			if (gd_concatenate_cigars(C[i].r, nx.r, C[i].v.str ? enc_rev : enc_for, (uint8_t)C[i].v.str, qlen_sum, R, (uint32_t)O.a, (uint32_t)O.b,
 			                          (uint32_t)O.q, (uint32_t)O.e, (uint32_t)O.q2, (uint32_t)O.e2) == 0) {
 				nx.valid = 0;

@@ -8,7 +8,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #define __host__
 #define __device__
@@ -62,6 +64,7 @@ int main(int argc, char **argv)
 	std::vector<const char *> pos;
 	const char *mmi_in = nullptr, *mmi_out = nullptr;
 	bool trace = false;
+	int n_threads = 1;
 	bool preset_seen = false, sr_variant = false;
 	auto preset = [&](const char *p) -> bool {
 		if (!strcmp(p, "map-hifi")) { O.k = 19, O.w = 19, O.a = 1, O.b = 4, O.q = 6, O.q2 = 26, O.e = 2, O.e2 = 1, O.occ_dist = 500, min_mid_occ = 50, max_mid_occ = 500; }
@@ -95,7 +98,8 @@ int main(int argc, char **argv)
 					preset_seen = true;
 					if (!preset(p)) { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
 				}
-			} else if (a == "-t" || a == "-o") ++i;
+			} else if (a == "-t") { v = argv[++i]; if (pass) n_threads = atoi(v) > 0 ? atoi(v) : 1; }
+			else if (a == "-o") ++i;
 			else if (a == "-a") {}
 			else if (a == "-k") { v = argv[++i]; if (pass) O.k = atoi(v); }
 			else if (a == "-w") { v = argv[++i]; if (pass) O.w = atoi(v); }
@@ -174,8 +178,13 @@ int main(int argc, char **argv)
 	const int g = O.a, bb = O.b < 0 ? O.b : -O.b;
 	int8_t mat[25];
 	for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? (int8_t)g : (int8_t)bb);
-	std::string out;
-	for (size_t ri = 0; ri < qs.size(); ++ri) {
+	// reads are independent: a few worker threads, results printed in input order (the oracle's scalar DP is the slow part)
+	std::vector<std::string> sam_of(qs.size()), trace_of(qs.size());
+	auto map_one = [&](size_t ri) {
+		std::string out;
+		char *tbuf = nullptr;
+		size_t tlen_ = 0;
+		FILE *terr = trace ? open_memstream(&tbuf, &tlen_) : nullptr;
 		const std::string &seq = qs[ri];
 		const int len = (int)seq.size();
 		std::vector<GdReg> regs;
@@ -189,7 +198,7 @@ int main(int argc, char **argv)
 			unsigned tot = gd_sketch2(enc.data(), len, O.w, O.k, O.pat, O.max_seeds, mv.data(), maxm, shift_n.data());
 			(void)tot;
 			const int shift = (int)gd_get_shift(V, mv.data(), shift_n.data(), O.pat.W);
-			if (trace) fprintf(stderr, "QR\t%s\nFinal shift: %d\n", qn[ri].c_str(), shift);
+			if (trace) fprintf(terr, "QR\t%s\nFinal shift: %d\n", qn[ri].c_str(), shift);
 			unsigned n_mv = 0;
 			const uint32_t cap = (O.flag & GD_F_FRAG_MODE) ? (O.max_frag_len == 0 ? 800u : (uint32_t)O.max_frag_len) : UINT32_MAX;
 			const unsigned tel = gd_sketch3(enc.data(), (unsigned)len, O.w, O.k, O.pat, shift, cap, mv.data(), maxm, &n_mv);
@@ -206,9 +215,9 @@ int main(int argc, char **argv)
 			GdLoc *sr = gd_sort_locs(ar.data(), tmp.data(), nr);
 			std::vector<GdLoc> srv(sr, sr + nr);
 			if (trace) {
-				fprintf(stderr, "RS n_a_for: %u, n_a_rev: %u\n", nf, nr);
-				for (unsigned i = 0; i < nf; ++i) fprintf(stderr, "SD\t%s\t%d\t+\t%u\n", R.seq[sfv[i].target >> 32].name.c_str(), (int32_t)sfv[i].target + 1 - (int32_t)tel, sfv[i].query);
-				for (unsigned i = 0; i < nr; ++i) fprintf(stderr, "SD\t%s\t%d\t-\t%u\n", R.seq[srv[i].target >> 32].name.c_str(), (uint32_t)srv[i].target + 1, srv[i].query);
+				fprintf(terr, "RS n_a_for: %u, n_a_rev: %u\n", nf, nr);
+				for (unsigned i = 0; i < nf; ++i) fprintf(terr, "SD\t%s\t%d\t+\t%u\n", R.seq[sfv[i].target >> 32].name.c_str(), (int32_t)sfv[i].target + 1 - (int32_t)tel, sfv[i].query);
+				for (unsigned i = 0; i < nr; ++i) fprintf(terr, "SD\t%s\t%d\t-\t%u\n", R.seq[srv[i].target >> 32].name.c_str(), (uint32_t)srv[i].target + 1, srv[i].query);
 			}
 			GdLrVoteOpt VO = {O.vt_dis, O.vt_nb_loc, O.bw, O.vt_cov, O.vt_f, O.vt_df1, O.vt_df2, O.k};
 			GdSrVoteOpt SO = {O.min_cnt, O.rec_threshold_frac, O.bw_frac, O.bw_min, O.bw_max, O.af_max_loc, cap, (O.flag & GD_F_FRAG_MODE) != 0};
@@ -217,15 +226,15 @@ int main(int argc, char **argv)
 			                         : gd_lr_candidates(sfv.data(), nf, srv.data(), nr, (uint32_t)len, (int32_t)tel, VO, vts);
 			const int dp_bw = sr_variant ? (int)gd_sr_bw(len, SO) : (int)O.bw;
 			if (trace && nc > 0) {
-				fprintf(stderr, "VT n: %u, len: %u\n", nc, (unsigned)len);
+				fprintf(terr, "VT n: %u, len: %u\n", nc, (unsigned)len);
 				for (unsigned i = 0; i < nc; ++i) {
 					const GdVt &p = vts[i];
 					if (sr_variant) { // SR/map.c:701-716
 						int32_t pos = p.first_target_loc + 1;
 						if (p.str) pos -= (len - 1);
-						fprintf(stderr, "VT\t%s (len: %u)\t%d\t%c\t[%u, %u]\t%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, pos, "+-"[p.str], p.first_query_loc, p.last_query_loc, p.score);
+						fprintf(terr, "VT\t%s (len: %u)\t%d\t%c\t[%u, %u]\t%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, pos, "+-"[p.str], p.first_query_loc, p.last_query_loc, p.score);
 					} else
-						fprintf(stderr, "VT\t%s (len: %u)\t[%u, %u]\t%c\t[%u, %u]\t%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, (uint32_t)p.first_target_loc,
+						fprintf(terr, "VT\t%s (len: %u)\t[%u, %u]\t%c\t[%u, %u]\t%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, (uint32_t)p.first_target_loc,
 						        (uint32_t)p.last_target_loc, "+-"[p.str], p.first_query_loc, p.last_query_loc, p.score);
 				}
 			}
@@ -235,16 +244,17 @@ int main(int argc, char **argv)
 				if (sr_variant) gd_sr_boxes(C, O, R, (uint32_t)len), nc = (unsigned)C.size();
 				else gd_lr_link_and_boxes(C, O, R, (uint32_t)len);
 				if (trace && !sr_variant) {
-					fprintf(stderr, "AVT n: %u, len: %u\n", nc, (unsigned)len);
+					fprintf(terr, "AVT n: %u, len: %u\n", nc, (unsigned)len);
 					for (unsigned i = 0; i < nc; ++i) {
 						const GdVt &p = C[i].v;
-						fprintf(stderr, "AVT\t%s (len: %u)\t[%u, %u]\t%c\t[%u, %u]\t%u\tc:%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, (uint32_t)p.first_target_loc,
+						fprintf(terr, "AVT\t%s (len: %u)\t[%u, %u]\t%c\t[%u, %u]\t%u\tc:%u\n", R.seq[p.chrom_id].name.c_str(), R.seq[p.chrom_id].len, (uint32_t)p.first_target_loc,
 						        (uint32_t)p.last_target_loc, "+-"[p.str], p.first_query_loc, p.last_query_loc, p.score, (unsigned)C[i].concat);
 					}
-					for (unsigned i = 0; i < nc; ++i)
-						fprintf(stderr, "BE\t%s, [%u, %u[ (chrom_len: %u) -> '%c' [%u, %u[ (read_len: %u)\n", R.seq[C[i].target_id].name.c_str(), C[i].target_start, C[i].target_end,
-						        R.seq[C[i].target_id].len, "+-"[C[i].v.str], // the reference prints the box of a '-' candidate before flipping it to read coordinates
-						        C[i].v.str ? (unsigned)len - 1 - C[i].query_end : C[i].query_start, C[i].v.str ? (unsigned)len - 1 - C[i].query_start : C[i].query_end, (unsigned)len);
+					for (unsigned i = 0; i < nc; ++i) { // the reference prints the box before it widens it for reads <= 300 bp, in strand coordinates (LR/map.c:1659-1675)
+						const GdVt &p = C[i].v;
+						fprintf(terr, "BE\t%s, [%u, %u[ (chrom_len: %u) -> '%c' [%u, %u[ (read_len: %u)\n", R.seq[C[i].target_id].name.c_str(), (uint32_t)p.first_target_loc, (uint32_t)p.last_target_loc,
+						        R.seq[C[i].target_id].len, "+-"[p.str], p.str ? (unsigned)len - 1 - p.last_query_loc : p.first_query_loc, p.str ? (unsigned)len - 1 - p.first_query_loc : p.last_query_loc, (unsigned)len);
+					}
 				}
 				std::vector<GdDpResult> dp(nc);
 				std::vector<gdo_extz_t> ez(nc);
@@ -262,10 +272,10 @@ int main(int argc, char **argv)
 						gdo_ksw_extd2((int)c.qlen, q, (int)c.tlen, t.data(), 5, mat, (int8_t)O.q, (int8_t)O.e, (int8_t)O.q2, (int8_t)O.e2, dp_bw, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez[i]);
 						dp[i] = {ez[i].score, ez[i].cigar, ez[i].n_cigar};
 					}
-					if (trace && !sr_variant) fprintf(stderr, "AL_SCORE: %d\n", dp[i].score);
+					if (trace && !sr_variant) fprintf(terr, "AL_SCORE: %d\n", dp[i].score);
 				}
 				if (sr_variant) gd_sr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs);
-				else gd_lr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs);
+				else gd_lr_finish(C, dp, O, R, (uint32_t)len, enc.data(), rev.data(), regs, terr);
 				for (unsigned i = 0; i < nc; ++i) free(ez[i].cigar);
 			}
 		}
@@ -275,13 +285,27 @@ int main(int argc, char **argv)
 				if ((O.flag & GD_F_NO_PRINT_2ND) && regs[j].id != regs[j].parent) continue;
 				out.clear();
 				gd_write_sam(out, R, qn[ri].c_str(), seq.c_str(), qual, len, regs, (int)j, O.flag);
-				puts(out.c_str());
+				sam_of[ri] += out, sam_of[ri] += '\n';
 			}
 		} else {
 			out.clear();
 			gd_write_sam(out, R, qn[ri].c_str(), seq.c_str(), qual, len, regs, -1, O.flag);
-			puts(out.c_str());
+			sam_of[ri] += out, sam_of[ri] += '\n';
 		}
+		if (terr) {
+			fclose(terr);
+			trace_of[ri].assign(tbuf, tlen_);
+			free(tbuf);
+		}
+	};
+	std::atomic<size_t> next_read{0};
+	std::vector<std::thread> workers;
+	for (int t = 0; t < n_threads; ++t)
+		workers.emplace_back([&] { for (size_t ri; (ri = next_read.fetch_add(1)) < qs.size();) map_one(ri); });
+	for (auto &w : workers) w.join();
+	for (size_t ri = 0; ri < qs.size(); ++ri) {
+		fputs(trace_of[ri].c_str(), stderr);
+		fputs(sam_of[ri].c_str(), stdout);
 	}
 	return 0;
 }

@@ -10,10 +10,19 @@ SR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sr")
 # seeding kernel overflows its first estimate and the batch is retried with the hard bound)
 # "*_edge": reads shorter than k / k+w, all-N, poly-A, lower case, IUPAC codes, chimeras, duplications, lengths around the 300 bp
 # switches of both variants, indels, reads flush with a contig start (golden: tools of the reference on these very files)
-SETS = {"hifi_edge": (LR, "edge_hifi", "hifi"), "ont_edge": (LR, "edge_ont", "ont"), "sr_edge": (SR, "edge", "sr"),
+# "hifi_sv" / "ont_sv": reads with one structural difference each (deletion, insertion, chimera, tandem duplication, inversion;
+# tools/synth.py --kind *_sv): second voting round, linked candidates, concatenate_cigars, supplementary and secondary records
+SETS = {"hifi_sv": (LR, "hifi_sv", "hifi"), "ont_sv": (LR, "ont_sv", "ont"), "hifi_edge": (LR, "edge_hifi", "hifi"), "ont_edge": (LR, "edge_ont", "ont"), "sr_edge": (SR, "edge", "sr"),
         "hifi_w1": (LR, "w1", "hifi"), "hifi": (LR, "hifi", "hifi"), "ont": (LR, "ont", "ont"), "sr": (SR, "sr", "sr"), "sr_var": (SR, "var", "sr")}
 # options of var.cmd that differ from the sr preset (README command): -N 5 -n 0.3,0.1 -s 40 --AF_max_loc 20
-OVERRIDES = {"hifi_w1": dict(k=15, w=1), "sr_var": dict(best_n=5, min_cnt=0.3, rec_threshold_frac=0.1, min_dp_max=40, AF_max_loc=20)}
+OVERRIDES = {"hifi_w1": dict(k=15, w=1), "ont_sv": dict(min_dp_max=4000),  # ont_sv.cmd: -s 4000 (reads of ~14 kbp)
+             "sr_var": dict(best_n=5, min_cnt=0.3, rec_threshold_frac=0.1, min_dp_max=40, AF_max_loc=20)}
+
+
+# kinds whose --print-seeds stage trace is committed next to the golden SAM (<stem>.trace.gz, oracle/make_golden.py), reduced
+# to the lines that start with one of TRACE_PREFIXES
+TRACED = ("hifi", "ont", "hifi_sv", "ont_sv", "sr")
+TRACE_PREFIXES = ("Final shift", "RS ", "SD\t", "VT\t", "AVT\t", "BE\t", "AL_SCORE", "CONQ", "CONT")
 
 
 def read_fasta(path):
@@ -41,6 +50,11 @@ def read_fastq(path):
 def golden_sam(kind):
     d, stem, _ = SETS[kind]
     return [l.rstrip("\n") for l in gzip.open(os.path.join(d, stem + ".golden.sam.gz"), "rt")]
+
+
+def trace_of(kind):
+    d, stem, _ = SETS[kind]
+    return [l.rstrip("\n") for l in gzip.open(os.path.join(d, stem + ".trace.gz"), "rt")]
 
 
 def reads_of(kind):

@@ -3,8 +3,8 @@
 The reference prints an unmapped read as `name 4 * 0 0 * * 0 0 SEQ QUAL rl:i:0 [comment]` (LR/format.c), so mapping awkward FASTA /
 FASTQ files against an unrelated contig with the reference binary (oracle/_ref, built from /root/reference by oracle/Makefile.ref)
 shows exactly which name, sequence, quality string and comment its kseq_read / mm_bseq_read3 produced for every record.  A
-committed fixture pins the same thing where the reference is absent: tests/golden/fastx/*.expected were written by this test's
-generator from the reference's output (tests/golden/fastx/README)."""
+committed fixture holds that view: tests/golden/fastx/*.expected.json, written by oracle/make_golden.py (never by a test) from the
+reference's output; where oracle/_ref is built the test also checks that the reference still says what the fixture says."""
 import gzip
 import json
 import os
@@ -14,77 +14,10 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, load_pkg
+from fastx_inputs import awkward_inputs, reference_view
 
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")
 GOLD = os.path.join(ROOT, "tests", "golden", "fastx")
-
-
-def _awkward_inputs(rng):
-    """name -> bytes of a FASTA/FASTQ file exercising the record grammar"""
-    def seq(n, alphabet=b"ACGT"):
-        return bytes(rng.choice(list(alphabet), size=n).tolist())
-
-    def wrap(s, w):
-        return b"\n".join(s[i:i + w] for i in range(0, len(s), w))
-
-    files = {}
-    # 1. plain 4-line FASTQ, comments after the name, one read with U and lower case
-    recs = []
-    for i in range(40):
-        s = seq(int(rng.integers(30, 400)), b"ACGTacgtUuN" if i % 7 == 0 else b"ACGT")
-        q = bytes(rng.integers(33, 74, size=len(s), dtype=np.uint8).tolist())
-        recs.append(b"@r%d comment %d\tmore\n" % (i, i) + s + b"\n+\n" + q + b"\n")
-    files["plain.fq"] = b"".join(recs)
-    # 2. multi-line FASTQ: wrapped sequence and quality, quality lines that start with '@' and '+', '+name' separator lines,
-    #    empty lines between records
-    recs = []
-    for i in range(30):
-        s = seq(int(rng.integers(61, 500)))
-        q = bytearray(rng.integers(35, 74, size=len(s), dtype=np.uint8).tolist())
-        q[0] = ord("@")
-        if len(q) > 60:
-            q[60] = ord("+") if i % 2 else ord("@")
-        recs.append(b"@m%d_%d\n" % (i // 2, 1 + i % 2) + wrap(s, 60) + b"\n+m%d\n" % i + wrap(bytes(q), 60) + b"\n" + (b"\n" if i % 3 == 0 else b""))
-    files["multiline.fq"] = b"".join(recs)
-    # 3. Windows line ends, with and without a comment
-    recs = []
-    for i in range(20):
-        s = seq(int(rng.integers(30, 200)))
-        q = bytes(rng.integers(40, 74, size=len(s), dtype=np.uint8).tolist())
-        recs.append(b"@w%d%s\r\n" % (i, b" c" if i % 2 else b"") + s + b"\r\n+\r\n" + q + b"\r\n")
-    files["crlf.fq"] = b"".join(recs)
-    # 4. multi-line FASTA, text before the first header, a record with an empty sequence, no newline at the end
-    recs = [b"leading text that is not a record\n"]
-    for i in range(25):
-        s = b"" if i == 11 else seq(int(rng.integers(30, 700)))
-        recs.append(b">f%d desc=%d\n" % (i, i) + (wrap(s, 70) + b"\n" if s else b""))
-    files["multi.fa"] = b"".join(recs).rstrip(b"\n")
-    # 5. FASTQ whose last record has a short quality string
-    files["truncated.fq"] = files["plain.fq"][:2000].rsplit(b"@r", 1)[0] + b"@last\nACGTACGTACGT\n+\nIIII\n"
-    # 6. a malformed record in the middle: the lines after it are swallowed / rescanned exactly as kseq_read does
-    body = files["plain.fq"].split(b"\n@r")
-    files["broken_mid.fq"] = b"\n@r".join(body[:12]) + b"\n@bad\nACGTACGTAC\n+\nII\n@r" + b"\n@r".join(body[12:])
-    return files
-
-
-def _reference_view(path, tmp_path, with_comment):
-    """[(name, seq, qual or None, comment or None)] as the reference binary parsed them"""
-    contig = os.path.join(str(tmp_path), "unrelated.fa")
-    if not os.path.exists(contig):
-        with open(contig, "w") as f:
-            f.write(">c\n" + "ACGTTGCA" * 400 + "\n")
-    cmd = [REF_BIN, "-t", "1", "-ax", "map-hifi", "-Z", "10", "-W", "2", "-i", "0.2", "-k", "19", "-w", "19", "-a"] + (["-y"] if with_comment else []) + [contig, path]
-    out = subprocess.run(cmd, capture_output=True, check=True).stdout
-    rows = []
-    for line in out.split(b"\n"):
-        if not line or line.startswith(b"@"):
-            continue
-        f = line.split(b"\t")
-        assert f[1] == b"4", "a read of the parser test mapped: " + line[:80].decode()
-        assert f[11].startswith(b"rl:i:")  # the one tag an unmapped record carries; -y appends the comment after it
-        comment = b"\t".join(f[12:]) if len(f) > 12 else None
-        rows.append((f[0], f[9], None if f[10] == b"*" else f[10], comment))
-    return rows
 
 
 def _ours(pkg, path, chunk, with_comment):
@@ -108,8 +41,7 @@ def _norm(rows, with_comment):
 @pytest.mark.parametrize("with_comment", [False, True])
 def test_reader_matches_the_reference_parser(tmp_path, with_comment):
     pkg = load_pkg()
-    files = _awkward_inputs(np.random.default_rng(31))
-    os.makedirs(GOLD, exist_ok=True)
+    files = awkward_inputs(np.random.default_rng(31))
     for name, data in files.items():
         for gz in (False, True):
             path = os.path.join(str(tmp_path), name + (".gz" if gz else ""))
@@ -117,14 +49,10 @@ def test_reader_matches_the_reference_parser(tmp_path, with_comment):
                 f.write(data)
             ours, sizes, trunc = _ours(pkg, path, 1500, with_comment)
             gold = os.path.join(GOLD, "%s.%s.expected.json" % (name, "y" if with_comment else "n"))
-            if os.path.exists(REF_BIN):
-                want = _reference_view(path, tmp_path, with_comment)
-                if not gz:
-                    with open(gold, "w") as f:  # refreshed wherever the reference is available; committed
-                        json.dump([[x.decode("latin1") if x is not None else None for x in row] for row in want], f)
-            else:
-                with open(gold) as f:
-                    want = [tuple(x.encode("latin1") if x is not None else None for x in row) for row in json.load(f)]
+            with open(gold) as f:
+                want = [tuple(x.encode("latin1") if x is not None else None for x in row) for row in json.load(f)]
+            if os.path.exists(REF_BIN):  # the committed fixture is the reference's view (also of the gzip'd file)
+                assert [tuple(r) for r in reference_view(REF_BIN, path, tmp_path, with_comment)] == want, (name, gz)
             assert _norm(ours, with_comment) == [tuple(w) for w in want], (name, gz)
             assert trunc == (name in ("truncated.fq", "broken_mid.fq"))
             # mm_bseq_read3's batching rule: a batch closes with the record that brings its bases to chunk_size

@@ -10,7 +10,7 @@ from fixture_io import LR, OVERRIDES, SETS, golden_sam, read_fasta, read_fastq, 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge"])
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge", "hifi_sv", "ont_sv"])
 def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
     base, stem, preset = SETS[kind]
     names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
@@ -27,9 +27,9 @@ def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
             assert a == b, (a[:300], b[:300])
         assert m.sam_batch(res, reads) == "".join(l + "\n" for l in want)  # the batch formatter (host threads) prints the same bytes
         # every DP of the HiFi fixture must have gone through the register-resident kernel
-        if kind == "hifi":
+        if kind in ("hifi", "hifi_sv"):
             assert gpu_ctx.last_kernel_mask() & 1
-        if kind == "ont":  # w = 1300: the two-blocks-per-lane kernel
+        if kind in ("ont", "ont_sv"):  # w = 1300: the two-blocks-per-lane kernel
             assert gpu_ctx.last_kernel_mask() & 8
         if kind == "sr":  # 150 x 150, w = 150 boxes: the 16-lane kernel
             assert gpu_ctx.last_kernel_mask() & 4

@@ -10,7 +10,7 @@ import subprocess
 import pytest
 
 from conftest import ROOT
-from fixture_io import LR, SETS, SR, cmd_of, golden_sam, reads_of
+from fixture_io import LR, SETS, SR, TRACE_PREFIXES, cmd_of, golden_sam, reads_of, trace_of
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +28,10 @@ def host_driver(tmp_path_factory):
     return exe, str(d)
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge"])
+THREADS = ["-t", str(min(8, os.cpu_count() or 1))]
+
+
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge", "hifi_sv", "ont_sv"])
 def test_host_path_matches_golden_sam(host_driver, kind, tmp_path):
     exe, d = host_driver
     base = SETS[kind][0]
@@ -36,7 +39,7 @@ def test_host_path_matches_golden_sam(host_driver, kind, tmp_path):
     with open(fq, "w") as f:
         for name, seq, qual in reads_of(kind):
             f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
-    out = subprocess.run([exe] + cmd_of(kind) + [os.path.join(d, os.path.basename(base), "ref.fa"), fq], capture_output=True, text=True, check=True)
+    out = subprocess.run([exe] + THREADS + cmd_of(kind) + [os.path.join(d, os.path.basename(base), "ref.fa"), fq], capture_output=True, text=True, check=True)
     got = out.stdout.rstrip("\n").split("\n")
     want = golden_sam(kind)
     assert len(got) == len(want)
@@ -114,39 +117,61 @@ def test_mmi_files_are_exchangeable_with_the_reference(host_driver, tmp_path, ki
     assert [l for l in back.rstrip("\n").split("\n") if not l.startswith("@")] == want
 
 
-@pytest.mark.parametrize("kind,n_reads", [("hifi", 12), ("ont", 6), ("sr", 400)])
-def test_stage_trace_matches_the_reference(host_driver, tmp_path, kind, n_reads):
-    """stage-level parity (the reference's --print-seeds trace): chosen pattern phase, sorted seed hits of both
-    strands, vote candidates before and after linking, DP boxes and DP scores, line for line.  Hits with equal targets may be
-    ordered differently by the two sorts, so the SD lines are compared as a multiset per read."""
-    variant = "sr" if kind == "sr" else "lr"
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "gdiet_%s_avx" % variant)
-    if not os.path.exists(ref_bin):
-        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+def _split_trace(lines):
+    """per read: the --print-seeds lines by stage (a read starts at its "Final shift" line)"""
+    per_read, cur = [], None
+    for line in lines:
+        if line.startswith("Final shift"):
+            cur = {"shift": line, "RS": [], "SD": [], "VT": [], "AVT": [], "BE": [], "AL": [], "CON": []}
+            per_read.append(cur)
+        elif cur is not None:
+            for key, prefix in (("RS", "RS "), ("SD", "SD\t"), ("VT", "VT\t"), ("AVT", "AVT\t"), ("BE", "BE\t"), ("AL", "AL_SCORE"), ("CON", "CON")):
+                if line.startswith(prefix):
+                    cur[key].append(line)
+    for r in per_read:
+        r["SD"].sort()
+    return per_read
+
+
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "hifi_sv", "ont_sv"])
+def test_stage_trace_matches_the_reference(host_driver, tmp_path, kind):
+    """stage-level parity (the reference's --print-seeds trace, committed as <kind>.trace.gz by oracle/make_golden.py):
+    chosen pattern phase, sorted seed hits of both strands, vote candidates before and after linking (second voting round
+    included), DP boxes, DP scores and the CONQ / CONT line pairs of every concatenate_cigars call, line for line.  Hits with
+    equal targets may be ordered differently by the two sorts, so the SD lines are compared as a multiset per read."""
     exe, d = host_driver
+    variant = "sr" if kind == "sr" else "lr"
     ref_fa = os.path.join(d, variant, "ref.fa")
     fq = str(tmp_path / "reads.fq")
+    reads = reads_of(kind)
     with open(fq, "w") as f:
-        for name, seq, qual in reads_of(kind)[:n_reads]:
+        for name, seq, qual in reads:
             f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
-
-    def trace(binary):
-        err = subprocess.run([binary] + cmd_of(kind) + ["--print-seeds", ref_fa, fq], capture_output=True, text=True, check=True).stderr
-        per_read, cur = [], None
-        for line in err.split("\n"):
-            if line.startswith("Final shift"):
-                cur = {"shift": line, "RS": [], "SD": [], "VT": [], "AVT": [], "BE": [], "AL": []}
-                per_read.append(cur)
-            elif cur is not None:
-                for key, prefix in (("RS", "RS "), ("SD", "SD\t"), ("VT", "VT\t"), ("AVT", "AVT\t"), ("BE", "BE\t"), ("AL", "AL_SCORE")):
-                    if line.startswith(prefix):
-                        cur[key].append(line)
-        for r in per_read:
-            r["SD"].sort()
-        return per_read
-
-    want, got = trace(ref_bin), trace(exe)
-    assert len(want) == len(got) == n_reads
+    err = subprocess.run([exe] + THREADS + cmd_of(kind) + ["--print-seeds", ref_fa, fq], capture_output=True, text=True, check=True).stderr
+    want, got = _split_trace(trace_of(kind)), _split_trace(l for l in err.split("\n") if l.startswith(TRACE_PREFIXES))
+    assert len(want) == len(got) == len(reads)
     for a, b in zip(want, got):
         assert a == b
     assert sum(len(r["SD"]) for r in want) > 100 and sum(len(r["VT"]) for r in want) > 0
+    if kind.endswith("_sv"):  # the fixtures exist for these stages
+        assert sum(len(r["CON"]) for r in want) >= 2 * 20
+
+
+def test_sv_fixtures_reach_concatenation_supplementary_and_secondary_records():
+    """what the *_sv goldens hold (>= 50 concatenate_cigars events, >= 30 supplementary, >= 5 secondary records)"""
+    flags, conq = {}, 0
+    for kind in ("hifi_sv", "ont_sv"):
+        for line in golden_sam(kind):
+            fl = int(line.split("\t")[1])
+            flags[fl] = flags.get(fl, 0) + 1
+        conq += sum(1 for l in trace_of(kind) if l.startswith("CONQ"))
+    assert conq >= 50 and flags.get(2048, 0) + flags.get(2064, 0) >= 30 and flags.get(256, 0) + flags.get(272, 0) >= 5
+
+
+def test_committed_goldens_are_what_the_reference_prints():
+    """oracle/make_golden.py in check mode: every committed golden SAM / trace / parser fixture is reproduced by the reference
+    binaries compiled here (skipped where /root/reference, hence oracle/_ref, does not exist)"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    r = subprocess.run(["python3", os.path.join(ROOT, "oracle", "make_golden.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -3,6 +3,11 @@
 
     python tools/synth.py ref  out.fa  --contigs 500000,300000,200000 [--repeats 20] [--seed 2]
     python tools/synth.py reads out.fq --ref out.fa --kind hifi|ont|sr --n 100 [--seed 5]
+    python tools/synth.py reads out.fq --ref out.fa --kind hifi_sv|ont_sv --n 150 [--seed 11] [--mean-len 9000]
+
+The *_sv kinds carry one structural difference from the reference per read at a random breakpoint -- deletion, insertion,
+chimera, tandem duplication, inversion (round-robin), 0.7-4.5 kbp -- so that the second voting round (vote_2), candidate
+linking, concatenate_cigars and the secondary / supplementary records of the LongReads path are exercised.
 """
 import argparse
 import sys
@@ -106,6 +111,59 @@ def make_reads(contigs, kind, n, seed):
     return out
 
 
+def revcomp(s):
+    return np.array([COMP[x] for x in s[::-1]], dtype=np.uint8)
+
+
+SV_KINDS = ("del", "ins", "chim", "dup", "inv")
+
+
+def make_sv_reads(contigs, kind, n, seed, mean_len=None):
+    """reads with one structural variant each (kinds round-robin, gap U[700,4500] at a breakpoint 20-80 % into the read)"""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(c) for c in contigs], dtype=np.float64)
+    if kind == "hifi_sv":
+        mu, sd, lo, hi = (mean_len or 15000), 0.13, 5000, 25000
+        sub, ins, dele = 0.002, 0.0005, 0.0005
+    else:
+        mu, sd, lo, hi = (mean_len or 20000), 0.2, 8000, 60000
+        sub, ins, dele = 0.03, 0.02, 0.02
+    out = []
+    for i in range(n):
+        sv = SV_KINDS[i % len(SV_KINDS)]
+        ln = int(np.clip(rng.normal(mu, mu * sd), lo, hi))
+        gap = int(rng.integers(700, 4501))
+        c = int(rng.choice(len(contigs), p=lens / lens.sum()))
+        ln = min(ln, len(contigs[c]) - gap - 2)
+        st = int(rng.integers(0, len(contigs[c]) - ln - gap))
+        bp = int(ln * rng.uniform(0.2, 0.8))
+        g = contigs[c]
+        if sv == "del":
+            s = np.concatenate([g[st:st + bp], g[st + bp + gap:st + ln + gap]])
+        elif sv == "ins":
+            s = np.concatenate([g[st:st + bp], BASES[rng.integers(0, 4, size=gap)], g[st + bp:st + ln]])
+        elif sv == "chim":
+            c2 = int(rng.choice(len(contigs), p=lens / lens.sum()))
+            l2 = min(ln - bp, len(contigs[c2]) - 2)
+            st2 = int(rng.integers(0, len(contigs[c2]) - l2))
+            tail = contigs[c2][st2:st2 + l2]
+            if rng.random() < 0.5:
+                tail = revcomp(tail)
+            s = np.concatenate([g[st:st + bp], tail])
+        elif sv == "dup":
+            gap = min(gap, bp)
+            s = np.concatenate([g[st:st + bp], g[st + bp - gap:st + ln]])
+        else:
+            gap = min(gap, ln - bp)
+            s = np.concatenate([g[st:st + bp], revcomp(g[st + bp:st + bp + gap]), g[st + bp + gap:st + ln]])
+        s = mutate(rng, s, sub, ins, dele)
+        rev = rng.random() < 0.5
+        if rev:
+            s = revcomp(s)
+        out.append(("%s_%d_%s%d_c%d_%d_%s" % (kind, i, sv, gap, c + 1, st, "-" if rev else "+"), s))
+    return out
+
+
 def write_fastq(path, reads):
     with open(path, "wb") as f:
         for name, s in reads:
@@ -122,9 +180,13 @@ if __name__ == "__main__":
     ap.add_argument("--kind", default="hifi")
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--mean-len", type=int, default=None)
     a = ap.parse_args()
     if a.what == "ref":
         write_fasta(a.out, make_ref([int(x) for x in a.contigs.split(",")], seed=2 if a.seed is None else a.seed, n_families=a.repeats))
     else:
         _, contigs = read_fasta(a.ref)
-        write_fastq(a.out, make_reads([c.copy() for c in contigs], a.kind, a.n, 5 if a.seed is None else a.seed))
+        if a.kind.endswith("_sv"):
+            write_fastq(a.out, make_sv_reads(contigs, a.kind, a.n, 11 if a.seed is None else a.seed, a.mean_len))
+        else:
+            write_fastq(a.out, make_reads([c.copy() for c in contigs], a.kind, a.n, 5 if a.seed is None else a.seed))
