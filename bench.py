@@ -12,11 +12,16 @@ Workload = BASELINE.json configs[3], the configuration the metric is quoted on:
 
 A "step" = one pass of the whole per-read path (sketch2/shift/sketch3, seed filter + lookup, hit sort, vote/vote_2 on the
 GPU; candidate geometry on host threads; window gather, exact-match, ksw_extd2 DP, backtrack on the GPU; mm_update_extra /
-concatenate_cigars / mm_set_sam_params on host threads) over one batch of reads that is already resident in HBM.  With the
+concatenate_cigars / mm_set_sam_params on host threads) over one batch of reads that is already resident in HBM.  Every step
+maps a DIFFERENT batch: ceil(200 000 / batch) = 40 distinct batches of 5120 reads are synthesised and uploaded before the timed
+region (configs[3]'s 200 k reads; the default --steps 40 goes through each of them once, more steps cycle).  With the
 default --inflight 3 steps i+1 and i+2 are submitted (gdiet_hip_map_submit) before step i is waited for, so their seeding / voting / host
 stages overlap the DP kernel of step i; all K batches are complete when the timed region ends (--inflight 1 runs them one at
 a time).  value = bases of reads with >= 1 alignment / wall time, summed over ranks (reads are sharded over GPUs, index
-replicated, no collective).
+replicated, no collective).  p50_read_latency_ms = median over the reads of the timed steps of (gdiet_hip_map_wait of their batch
+returned - gdiet_hip_map_submit was called): every read of a batch completes with its batch.  config.with_upload: the same
+steps once more, outside the timed region, with the reads handed over as HOST buffers (gdiet_hip_batch_upload = encode + H2D inside
+the pipeline): the PCIe-inclusive rate, never `value`.
 
 roofline: dominant kernel = ksw_extd2_wave_kernel<64, 0, true> (DP + its own backtrack); achieved = algorithmic bytes of the
 launch (per alignment (qlen+tlen-1)*min(w+1,qlen,tlen) + (qlen+tlen) + qlen + ceil(tlen/2)) / its duration, the mean
@@ -80,48 +85,106 @@ def synth_reference(total_mbp, seed=2):
     return ["chr%d" % (i + 1) for i in range(len(contigs))], contigs
 
 
-def synth_hifi_reads(rng, contigs, n, only_contig=None):
+def synth_hifi_reads(rng, contigs, n, only_contig=None, first=0):
+    """SURVEY 8d HiFi reads: length N(15000, 2000) clipped to [5000, 25000], sub 0.2 % / ins 0.1 % / del 0.1 %, half of them
+    reverse-complemented.  Error positions are drawn as counts (binomial) + positions, not as one uniform per base: 40 batches
+    of 5120 reads have to be made before the timed region."""
     lens = np.array([len(c) for c in contigs], np.float64)
+    pc = lens / lens.sum()
     out = []
     for i in range(n):
         ln = int(np.clip(rng.normal(15000, 2000), 5000, 25000))
-        c = only_contig if only_contig is not None else int(rng.choice(len(contigs), p=lens / lens.sum()))
+        c = only_contig if only_contig is not None else int(rng.choice(len(contigs), p=pc))
         ln = min(ln, len(contigs[c]) - 2)
         st = int(rng.integers(0, len(contigs[c]) - ln))
         s = contigs[c][st:st + ln].copy()
-        m = np.flatnonzero((rng.random(ln) < 0.002) & (s != 78))
+        m = rng.integers(0, ln, size=rng.binomial(ln, 0.002))
+        m = m[s[m] != 78]
         if len(m):
             s[m] = BASES[(np.searchsorted(BASES, s[m]) + rng.integers(1, 4, size=len(m))) & 3]
-        s = s[~(rng.random(ln) < 0.001)]
-        ip = np.flatnonzero(rng.random(len(s)) < 0.001)
-        s = np.insert(s, ip, BASES[rng.integers(0, 4, size=len(ip))])
+        d = rng.integers(0, ln, size=rng.binomial(ln, 0.001))
+        if len(d):
+            s = np.delete(s, d)
+        ip = rng.integers(0, len(s), size=rng.binomial(len(s), 0.001))
+        if len(ip):
+            s = np.insert(s, ip, BASES[rng.integers(0, 4, size=len(ip))])
         if rng.random() < 0.5:
             s = COMP[s[::-1]]
-        out.append(("r%d_c%d_%d" % (i, c + 1, st), s.tobytes()))
+        out.append(("r%d_c%d_%d" % (first + i, c + 1, st), s.tobytes()))
     return out
 
 
-def cpu_baseline_reference(names, contigs, rng, cores, budget_s=25.0):
-    """the reference's own GDiet_avx on the host: index the smallest contig with -d, then time mapping only"""
+def shared_reference(total_mbp, local_rank, local_world, barrier, tag):
+    """the synthetic reference once per NODE: local rank 0 synthesises it into a file in /dev/shm, the other ranks of the node map
+    that file (np.memmap) instead of spending 6 s and 3 GB each on an identical copy.  Returns (names, contigs, seconds, how)"""
+    t0 = time.time()
+    if local_world <= 1:
+        names, contigs = synth_reference(total_mbp, seed=2)
+        return names, contigs, time.time() - t0, "synthesised in-process"
+    path = "/dev/shm/gdiet_bench_ref_%s_%d.u8" % (tag, int(total_mbp))
+    if local_rank == 0:
+        names, contigs = synth_reference(total_mbp, seed=2)
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            for c in contigs:
+                f.write(c.tobytes())
+        with open(path + ".json", "w") as f:
+            json.dump({"names": names, "lens": [len(c) for c in contigs]}, f)
+        os.replace(tmp, path)
+    barrier()
+    if local_rank != 0:
+        meta = json.load(open(path + ".json"))
+        mm = np.memmap(path, dtype=np.uint8, mode="r")
+        off = np.concatenate([[0], np.cumsum(meta["lens"])])
+        names, contigs = meta["names"], [mm[off[i]:off[i + 1]] for i in range(len(meta["lens"]))]
+    barrier()
+    if local_rank == 0:  # every rank has the file mapped: the name can go (the pages live as long as the mappings)
+        for f in (path, path + ".json"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+    return names, contigs, time.time() - t0, "synthesised by local rank 0, shared through /dev/shm"
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_reference(names, contigs, rng, cores, which="largest"):
+    """the reference's own GDiet_avx on the host: index ONE contig with -d (outside the timing), then time mapping only.
+    which = "largest" (chr1-sized, the default: indexing the whole 3.1 Gbp reference with the reference binary takes minutes and
+    ~20 GB) | "smallest" | "whole".  The reads are drawn from the indexed contig(s) by the generator of the GPU leg."""
     exe = os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")
-    c = int(np.argmin([len(x) for x in contigs]))
-    reads = synth_hifi_reads(rng, contigs, 2048, only_contig=c)  # ~31 Mbases: seconds of wall time on the host's cores
+    lens = [len(x) for x in contigs]
+    sel = list(range(len(contigs))) if which == "whole" else [int(np.argmax(lens) if which == "largest" else np.argmin(lens))]
+    sub = [contigs[i] for i in sel]
+    reads = synth_hifi_reads(rng, sub, 2048, only_contig=None if which == "whole" else 0)  # ~31 Mbases: seconds of wall time on the host's cores
     hifi = ("-ax map-hifi -Z 10 -W 2 -i 0.2 -k 19 -w 19 -N 1 -r 1000 --vt_dis=650 --vt_nb_loc=5 --vt_df1=0.0106 --vt_df2=0.2 -s 400 "
             "--vt_cov 0.04 --max_min_gap=4000 --vt_f=0.04 --sort=merge --frag=no -F200,1 --secondary=yes -a").split()
     with tempfile.TemporaryDirectory() as d:
         fa, fq, mmi = os.path.join(d, "c.fa"), os.path.join(d, "r.fq"), os.path.join(d, "c.mmi")
         with open(fa, "wb") as f:
-            f.write(b">" + names[c].encode() + b"\n" + contigs[c].tobytes() + b"\n")
+            for i in sel:
+                f.write(b">" + names[i].encode() + b"\n" + np.asarray(contigs[i]).tobytes() + b"\n")
         with open(fq, "wb") as f:
             for nm, s in reads:
                 f.write(b"@" + nm.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+        t0 = time.time()
         subprocess.run([exe, "-t", str(cores)] + hifi + ["-d", mmi, fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        t_index = time.time() - t0
         # `cores` = the CPUs this container may use (cgroup quota / affinity, not the host's thread count).  The reference's thread
         # scaling is not perfect (its per-alignment 30 MB backtrace allocations serialise in the kernel), so the baseline is the BEST
         # of a few thread counts on the same sample, not simply -t <all cores>
         best, tried = None, []
         for t in sorted({max(1, cores // 2), cores, 2 * cores}):
-            r = subprocess.run([exe, "-t", str(t)] + hifi + [mmi, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            r = subprocess.run([exe, "-t", str(t)] + hifi + [mmi, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
             err = r.stderr.decode(errors="ignore")
             m = re.search(r"\[M::main::([0-9.]+)\*[0-9.]+\] loaded/built the index", err)
             load = float(m.group(1)) if m else 0.0
@@ -134,9 +197,12 @@ def cpu_baseline_reference(names, contigs, rng, cores, budget_s=25.0):
             tried.append("-t %d: %.2f Mbases/s" % (t, v / 1e6))
             if best is None or v > best[0]:
                 best = (v, t)
-    return {"value": best[0], "unit": "mapped bases/s", "cores": best[1], "kind": "reference",
-            "sample": "%d HiFi reads (%d bases) drawn from the smallest contig (%s, %d bp), GDiet_avx with a prebuilt .mmi of that "
-                      "contig, mapping wall time only (index load excluded); best of %s" % (len(reads), sum(len(s) for _, s in reads), names[c], len(contigs[c]), "; ".join(tried))}
+    what = {"largest": "the largest contig", "smallest": "the smallest contig", "whole": "the whole reference"}[which]
+    return {"value": best[0], "unit": "mapped bases/s", "cores": best[1], "kind": "reference", "cpu_model": cpu_model(), "cpus_usable": cores,
+            "sample": "%d HiFi reads (%d bases, the GPU leg's generator) drawn from %s (%s, %d bp), GDiet_avx with a .mmi of it prebuilt in %.0f s "
+                      "(outside the timing), mapping wall time only (index load excluded); best of %s"
+                      % (len(reads), sum(len(s) for _, s in reads), what, "+".join(names[i] for i in sel) if which != "whole" else "%d contigs" % len(sel),
+                         sum(lens[i] for i in sel), t_index, "; ".join(tried))}
 
 
 def cpu_baseline_port(reads_enc, budget_s=12.0):
@@ -179,17 +245,23 @@ def self_check(res, res_again, reads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps; 40 x 5120 reads = configs[3]'s 200 k reads, every step a different batch")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=5120,
                     help="reads per step per GPU (5120 reads = ~9 400 alignments: just under two rounds of the 5 120 resident wavefront slots; "
                          "measured best of 4096..6144; its backtrace arena is 175 GB of the 288 GB)")
+    ap.add_argument("--total-reads", type=int, default=200000, help="reads of the workload (configs[3]); ceil(total / batch) distinct batches are made, at most --steps")
     ap.add_argument("--ref-mbp", type=float, default=float(os.environ.get("GDIET_BENCH_REF_MBP", "3088")),
                     help="size of the synthetic reference in Mbp (default: GRCh38-sized)")
     ap.add_argument("--lanes", type=int, default=1, help="software-pipeline depth inside a step (gdiet_hip_set_map_lanes)")
     ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="batches in flight (gdiet_hip_map_submit/_wait): 2 overlaps the seeding/voting/host stages of step i+1 with the DP kernel of step i")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank maps its own --batch reads per step (the contract's default); strong = ONE read set, each "
+                         "batch cut into contiguous ranges of equal DP cost (read_ranges_by_cost), one per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-ref", default="largest", choices=["largest", "smallest", "whole"], help="what the reference binary indexes for the CPU baseline")
+    ap.add_argument("--no-upload-pass", action="store_true", help="skip the PCIe-inclusive pass (config.with_upload)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on a one-GPU box)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK)")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads of the post-processing pool (default: the CPUs this container may use / ranks)")
@@ -199,6 +271,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    local_rank = local
     import torch.distributed as dist
     if args.device >= 0:
         local = args.device
@@ -213,90 +287,164 @@ def main():
     from __graft_entry__ import _load_pkg
     pkg = _load_pkg()
     pkg_cpus = pkg.effective_cpus()
-    cores = max(1, pkg_cpus // max(1, world))  # CPUs this container may use (cgroup quota, affinity), shared by the ranks of the node
+    cores = max(1, pkg_cpus // max(1, local_world))  # CPUs this container may use (cgroup quota, affinity), shared by the ranks of the node
     ctx = pkg.Context(local)
 
-    t_setup = time.time()
-    names, contigs = synth_reference(args.ref_mbp, seed=2)  # the same reference on every rank (replicated index)
-    t_ref = time.time() - t_setup
+    # the same reference on every rank (replicated index): synthesised once per node
+    names, contigs, t_ref, ref_how = shared_reference(args.ref_mbp, local_rank, local_world, (lambda: dist.barrier()) if world > 1 else (lambda: None),
+                                                      os.environ.get("MASTER_PORT", "0"))
     t1 = time.time()
     mapper = pkg.Mapper(ctx, names, contigs, preset="hifi", n_threads=cores)
-    mapper.set_host_threads(args.host_threads or cores)  # N ranks on one node share its cores
+    host_threads = args.host_threads or cores
+    mapper.set_host_threads(host_threads)  # N ranks on one node share its cores
     t_index = time.time() - t1
-    rng = np.random.default_rng(pkg.rank_seed(5, rank))  # HiFi reads seed 5 (+rank: read-sharded weak scaling)
-    reads = synth_hifi_reads(rng, contigs, args.batch)
-    batch = mapper.upload([s for _, s in reads])
-    read_lens = np.array([len(s) for _, s in reads])
+    # ---- the read set: distinct batches, uploaded before the timed region (value = inputs resident in HBM)
+    n_distinct = max(1, min(args.steps, -(-args.total_reads // args.batch)))
+    t2 = time.time()
+    batches = []  # (device batch, reads [(name, bytes)], read_lens)
+    if args.scaling == "strong" and world > 1:
+        rng = np.random.default_rng(5)  # ONE read set, identical on every rank; each rank keeps its cost-balanced contiguous share
+        for b in range(n_distinct):
+            allr = synth_hifi_reads(rng, contigs, args.batch, first=b * args.batch)
+            bounds = pkg.read_ranges_by_cost([len(s) for _, s in allr], world, band=W_HIFI)
+            mine = allr[bounds[rank]:bounds[rank + 1]]
+            batches.append((mapper.upload([s for _, s in mine]), mine, np.array([len(s) for _, s in mine])))
+    else:
+        rng = np.random.default_rng(pkg.rank_seed(5, rank))  # HiFi reads seed 5 (+rank: read-sharded weak scaling)
+        for b in range(n_distinct):
+            reads = synth_hifi_reads(rng, contigs, args.batch, first=b * args.batch)
+            batches.append((mapper.upload([s for _, s in reads]), reads, np.array([len(s) for _, s in reads])))
+    t_reads = time.time() - t2
 
     clock = pkg.JobClock(dist if world > 1 else None, dev, lambda: torch.cuda.synchronize(dev))
-    res = None
     mapper.set_lanes(args.lanes)
     if args.inflight > 1:
         mapper.set_inflight(args.inflight)
-    def run_steps(k, stages=None, kern=None):
-        """k passes over the batch; with --inflight N the next N-1 steps are submitted before step i is waited for.
-        stages / kern: per completed step, the stage seconds and the DP / backtrack kernel times of THAT step's launch (HIP
-        events on the stream it was launched on, read after the step has completed)"""
+    all_cells = [0, 0]  # DP cells / launches of EVERY step made by this process (the PMC summaries divide their counters by these)
+    step_no = [0]
+
+    def run_steps(k, rec=None, host_buffers=False):
+        """k steps, each on the next batch of the cycle; with --inflight N the next N-1 steps are submitted before step i is waited
+        for.  rec: dict of lists filled per completed step (stage seconds, kernel ms of THAT step's launch -- HIP events on the
+        stream it was launched on --, its DP work, its mapped bases, submit -> wait-return latency).  host_buffers: the reads go in
+        as host buffers (gdiet_hip_batch_upload inside the step) instead of the resident batch."""
         last, open_t = None, []
 
-        def done():
-            if stages is not None:
-                stages.append(mapper.stage_seconds())
-            if kern is not None:
-                kern.append(ctx.last_kernel_ms())
+        def finish(item):
+            ticket, bi, t_sub, tmp_batch = item
+            res = mapper.wait(ticket) if ticket is not None else None
+            return res, bi, t_sub, tmp_batch
+
+        def done(res, bi, t_sub, tmp_batch):
+            t_done = time.perf_counter()
+            cells, alg = ctx.last_dp_work()
+            all_cells[0] += cells
+            all_cells[1] += 1
+            if tmp_batch is not None:
+                mapper.free_batch(tmp_batch)
+            if rec is not None:
+                nr = np.frombuffer(res.n_regs, dtype=np.int32, count=res.n) if res.n else np.zeros(0, np.int32)
+                rec["stages"].append(mapper.stage_seconds())
+                rec["kern"].append(ctx.last_kernel_ms())
+                rec["work"].append((cells, alg))
+                rec["mapped_bases"].append(int(batches[bi][2][nr > 0].sum()))
+                rec["mapped_reads"].append(int((nr > 0).sum()))
+                rec["latency"].append(t_done - t_sub)
+                rec["aligns"].append(int(nr.sum()))
+            return res
+
         for _ in range(k):
+            bi = step_no[0] % len(batches)
+            step_no[0] += 1
+            t_sub = time.perf_counter()
+            tmp_batch = None
+            dbatch = batches[bi][0]
+            if host_buffers:
+                tmp_batch = dbatch = mapper.upload([s for _, s in batches[bi][1]])
             if args.inflight == 1:
-                last = mapper.map_uploaded(batch)  # returns when every read of the batch has its records on the host
-                done()
+                res = mapper.map_uploaded(dbatch)  # returns when every read of the batch has its records on the host
+                last = (done(res, bi, t_sub, tmp_batch), bi)
             else:
-                open_t.append(mapper.submit(batch))
+                open_t.append((mapper.submit(dbatch), bi, t_sub, tmp_batch))
                 if len(open_t) == args.inflight:
-                    last = mapper.wait(open_t.pop(0))
-                    done()
+                    r = finish(open_t.pop(0))
+                    last = (done(*r), r[1])
         while open_t:
-            last = mapper.wait(open_t.pop(0))
-            done()
+            r = finish(open_t.pop(0))
+            last = (done(*r), r[1])
         return last
 
     run_steps(args.inflight)  # set-up, like the index build: each lane allocates its device scratch on its first batch
-    res = run_steps(args.warmup)
+    run_steps(args.warmup)
     clock.start()  # synchronize + barrier + synchronize
-    kern, stages = [], []
-    res = run_steps(args.steps, stages, kern)  # every record of all K batches is on the host when this returns
+    rec = {k: [] for k in ("stages", "kern", "work", "mapped_bases", "mapped_reads", "latency", "aligns")}
+    res, res_bi = run_steps(args.steps, rec)  # every record of all K batches is on the host when this returns
     elapsed = clock.stop()  # synchronize + barrier
-    # for reference: the same launch once more with nothing else on the GPU (outside the timed region)
+    # the PCIe-inclusive figure (never `value`): the same kind of steps with the reads handed over as host buffers
+    with_upload = None
+    if not args.no_upload_pass:
+        k2 = min(args.steps, 10)
+        rec2 = {k: [] for k in rec}
+        t3 = time.perf_counter()
+        run_steps(k2, rec2, host_buffers=True)
+        torch.cuda.synchronize(dev)
+        dt2 = time.perf_counter() - t3
+        with_upload = {"steps": k2, "ms_per_step": 1e3 * dt2 / k2, "bases_per_s_this_rank": sum(rec2["mapped_bases"]) / dt2,
+                       "note": "gdiet_hip_batch_upload (host threads encode, one H2D copy) + submit per step; outside the timed region"}
+    # for reference: the last launch once more with nothing else on the GPU (outside the timed region)
     mapper.set_lanes(1)
-    res1 = mapper.map_uploaded(batch)
+    res1 = mapper.map_uploaded(batches[res_bi][0])
     dp_alone = ctx.last_kernel_ms()[0]
+    all_cells[0] += ctx.last_dp_work()[0]
+    all_cells[1] += 1
     # size-independent self-checks at full size (outside the timed region): the pipelined steps and this synchronous pass give the
     # same records (idempotence); every CIGAR consumes exactly its query and reference interval; the primary record of a mapped
     # read lies where the read was drawn from (the read names carry contig and start)
-    check = self_check(res, res1, reads)
+    check = self_check(res, res1, batches[res_bi][1])
     del res1
 
-    mapped = np.array([res.n_regs[i] > 0 for i in range(len(reads))])
-    bases_step = int(read_lens[mapped].sum())
-    elapsed, total_bases = clock.aggregate(elapsed, float(bases_step) * args.steps)  # MAX over ranks, SUM over ranks
+    bases_timed = float(sum(rec["mapped_bases"]))
+    elapsed, total_bases = clock.aggregate(elapsed, bases_timed)  # MAX over ranks, SUM over ranks
 
     if rank == 0:
-        dp = float(np.mean([d for d, _ in kern]))
-        bt = float(np.mean([b for _, b in kern]))
-        # algorithmic bytes of the DP launch (every candidate box the path aligned), counted by the library from the lengths
-        n_align = sum(res.n_regs[i] for i in range(len(reads)))
-        cells, alg = ctx.last_dp_work()
-        achieved = alg / (dp * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this very command
-        # (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json); only quoted when it was measured on the same launch (same cells)
-        traffic, traffic_src = None, None
+        dp_ms = np.array([d for d, _ in rec["kern"]], np.float64)
+        bt = float(np.mean([b for _, b in rec["kern"]]))
+        cells = np.array([c for c, _ in rec["work"]], np.float64)
+        alg = np.array([a for _, a in rec["work"]], np.float64)
+        # algorithmic bytes of the DP launches (every candidate box the path aligned, counted by the library from the lengths) over
+        # the time those launches took
+        achieved = alg.sum() / (dp_ms.sum() * 1e-3) / 1e9
+        dp = float(dp_ms.mean())
+        cells_launch = float(cells.mean())
+        # per-cell figures from the PMC passes of this very command (tools/pmc_traffic.py, tools/pmc_valu.py -> profiles/*.json)
+        traffic, traffic_src, valu = None, None, {}
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
             try:
                 t = json.load(open(f))
-                if abs(t.get("dp_cells_per_launch", -1) - cells) <= 0.001 * cells:
-                    traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                if "traffic_bytes_per_cell" in t:
+                    traffic, traffic_src = t["traffic_bytes_per_cell"] * cells_launch, os.path.relpath(f, ROOT)
                     break
             except Exception:
                 pass
-        st = np.mean(np.array(stages), axis=0)
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")), reverse=True):
+            try:
+                t = json.load(open(f))
+                if "valu_insts_per_cell" in t:
+                    insts = t["valu_insts_per_cell"] * cells_launch
+                    # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32; 1024 SIMDs at 2.4 GHz
+                    valu = {"valu_insts_per_cell": t["valu_insts_per_cell"], "salu_insts_per_cell": t.get("salu_insts_per_cell"),
+                            "valu_insts_per_1024_cell_row": 1024 * t["valu_insts_per_cell"],
+                            "valu_util": insts * 2.0 / (1024 * 2.4e9 * dp * 1e-3),
+                            "valu_util_note": "PMC SQ_INSTS_VALU of this kernel per cell (%s) x this run's cells per launch x 2 cycles (SIMD-32 issue peak, "
+                                              "MI355X_MICROARCH.md) / (1024 SIMDs x 2.4 GHz x this run's kernel time); measured issue cost of the kernel's "
+                                              "packed-16 instruction mix: ~4.2 cycles (profiles/r02_valu_issue.md), against which the kernel is at ~93 %%"
+                                              % os.path.relpath(f, ROOT),
+                            "simd_cycles_per_valu_inst_pmc": t.get("simd_cycles_per_valu_inst"), "valu_active_frac_pmc": t.get("valu_active_frac")}
+                    break
+            except Exception:
+                pass
+        st = np.mean(np.array(rec["stages"]), axis=0)
+        n_reads_step = int(np.mean([len(b[1]) for b in batches]))
         out = {
             "metric": "mapped bases/sec (whole node), HiFi map-hifi k19w19",
             "value": total_bases / elapsed,
@@ -306,41 +454,56 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "p50_read_latency_ms": 1e3 * elapsed / args.steps * args.inflight,
-            "config": {"workload": "BASELINE configs[3]: GDiet-LongReads -ax map-hifi k19 w19 -Z 10 -W 2 -i 0.2 -r 1000 ..., synthetic ~15 kbp HiFi reads vs "
-                                   "synthetic reference of %.0f Mbp in 24 contigs (GRCh38-sized = 3088)" % args.ref_mbp,
-                       "reads_per_step_per_gpu": len(reads), "bases_per_step_per_gpu": int(read_lens.sum()), "mapped_fraction": float(mapped.mean()),
-                       "alignments_per_step": int(n_align), "index_keys": int(mapper.n_keys()), "mid_occ": int(mapper.mid_occ),
-                       "setup_s": {"reference": round(t_ref, 1), "index_build_upload": round(t_index, 1)},
+            "p50_read_latency_ms": 1e3 * float(np.median(rec["latency"])),
+            "config": {"workload": "BASELINE configs[3]: GDiet-LongReads -ax map-hifi k19 w19 -Z 10 -W 2 -i 0.2 -r 1000 ..., %d synthetic ~15 kbp HiFi reads in %d distinct "
+                                   "batches vs synthetic reference of %.0f Mbp in 24 contigs (GRCh38-sized = 3088)" % (sum(len(b[1]) for b in batches), len(batches), args.ref_mbp),
+                       "reads_per_step_per_gpu": n_reads_step, "bases_per_step_per_gpu": int(np.mean([b[2].sum() for b in batches])),
+                       "distinct_batches": len(batches), "reads_timed_this_rank": int(sum(len(batches[i % len(batches)][1]) for i in range(args.steps))),
+                       "mapped_fraction": float(sum(rec["mapped_reads"])) / max(1, sum(len(batches[i % len(batches)][1]) for i in range(args.steps))),
+                       "alignments_per_step": float(np.mean(rec["aligns"])), "index_keys": int(mapper.n_keys()), "mid_occ": int(mapper.mid_occ),
+                       "setup_s": {"reference": round(t_ref, 1), "reference_how": ref_how, "index_build_upload": round(t_index, 1), "reads_synth_upload": round(t_reads, 1)},
                        "stage_s_per_step": {"seed_kernel": st[0], "vote_kernel": st[1], "host_geometry": st[2], "gather_dp_backtrack": st[3],
                                             "host_postprocess": st[4], "other": st[5]},
-                       "p50_read_latency_note": "every read of a batch completes with its batch; with 2 batches in flight a batch takes ~2 x ms_per_step from submit to wait",
-                       "batches_in_flight": args.inflight, "self_check": check,
-                       "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": args.host_threads or cores, "pipeline_lanes": args.lanes},
-            "roofline": {"bound": "hbm", "kernel": "ksw_extd2_wave_kernel<64, 0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(alg), "dp_cells_per_launch": int(cells), "gcups": cells / (dp * 1e-3) / 1e9, "kernel_ms": dp,
-                         "kernel_ms_note": "mean over the K timed launches (HIP events on each launch's stream); the 64-lane kernel walks its own "
-                                           "alignments back, so this is DP + backtrack; the other batches' seeding/voting kernels share the GPU",
-                         "kernel_ms_alone": dp_alone, "backtrack_kernel_ms": bt},
+                       "p50_read_latency_note": "median over the timed steps of (gdiet_hip_map_wait returned - gdiet_hip_map_submit called) of the read's batch; "
+                                                "every read of a batch completes with its batch; p10 / p90: %.1f / %.1f ms"
+                                                % (1e3 * float(np.percentile(rec["latency"], 10)), 1e3 * float(np.percentile(rec["latency"], 90))),
+                       "batches_in_flight": args.inflight, "self_check": check, "with_upload": with_upload,
+                       "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": host_threads,
+                       "cpus_usable_on_node": pkg_cpus, "pipeline_lanes": args.lanes},
+            "roofline": dict({"bound": "hbm", "kernel": "ksw_extd2_wave_kernel<64, 0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                              "algorithmic_bytes_per_launch": float(alg.mean()), "dp_cells_per_launch": cells_launch,
+                              "dp_cells_all_launches": int(all_cells[0]), "dp_launches": int(all_cells[1]),
+                              "gcups": cells.sum() / (dp_ms.sum() * 1e-3) / 1e9, "kernel_ms": dp,
+                              "kernel_ms_note": "mean over the K timed launches (HIP events on each launch's stream); the 64-lane kernel walks its own "
+                                                "alignments back, so this is DP + backtrack; the other batches' seeding/voting kernels share the GPU",
+                              "kernel_ms_alone": dp_alone, "backtrack_kernel_ms": bt}, **valu),
         }
+        # N ranks share the node's CPUs: the host stages of a step must stay hidden behind its DP kernel
+        if st[2] + st[4] > 0.8 * dp * 1e-3:
+            out["config"]["host_bound_warning"] = ("host stages %.1f ms per step with %d threads against a %.1f ms DP kernel: this rank is host-bound"
+                                                   % (1e3 * (st[2] + st[4]), host_threads, dp))
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
-            port_reads = [np.searchsorted(BASES, np.frombuffer(s, np.uint8)).clip(0, 3).astype(np.uint8) for _, s in reads[:64]]
+            port_reads = [np.searchsorted(BASES, np.frombuffer(s, np.uint8)).clip(0, 3).astype(np.uint8) for _, s in batches[0][1][:64]]
             try:  # the reference binary itself where it travelled with the repo (and runs on this host's CPU) ...
                 if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")):
                     raise FileNotFoundError("oracle/_ref/gdiet_lr_avx")
-                out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), pkg_cpus)
+                out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), pkg_cpus, args.cpu_baseline_ref)
             except Exception as ex:  # ... else the DP stage of the oracle port; the baseline must never take the benchmark line down
                 try:
                     out["cpu_baseline"] = cpu_baseline_port(port_reads)
                     out["cpu_baseline"]["sample"] += " (reference binary unavailable: %r)" % (ex,)
                 except Exception as ex2:
                     out["cpu_baseline"] = {"value": None, "unit": "mapped bases/s", "cores": 0, "kind": "port", "sample": "failed: %r / %r" % (ex, ex2)}
+            if out["cpu_baseline"].get("value"):
+                out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]  # (vs_baseline stays null: BASELINE.md publishes no number in this metric)
         print(json.dumps(out))
-    mapper.free_batch(batch)
+    for b in batches:
+        mapper.free_batch(b[0])
     mapper.close()
     if world > 1:
         dist.destroy_process_group()

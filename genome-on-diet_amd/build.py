@@ -19,7 +19,9 @@ def build_hip(force=False, verbose=False):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB, SRC, "-lz"]
+    # max-ilp scheduling: the DP row loop is one long block of dependent packed-16 operations; the default scheduler leaves 40 hazard
+    # s_nop in it (a VALU instruction reading the result of the VOP3P instruction right before it), this one 8: -1 % kernel time
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-o", LIB, SRC, "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -69,6 +69,7 @@ struct gdiet_ctx {
 	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
 	bool async_busy[4] = {false, false, false, false};
 	std::mutex async_mu;               // guards the ticket bookkeeping of submit / wait
+	std::vector<void *> open_tickets;  // gdiet_map_ticket* submitted and not yet waited for (joined by gdiet_hip_destroy)
 	std::vector<std::vector<uint8_t>> enc_pool; // host buffers of destroyed read batches, reused by the next uploads
 	std::mutex enc_mu;
 	int async_next = 0, async_depth = 2;
@@ -207,10 +208,12 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 }
 
 static void gd_pool_free(void *pool); // map_pipeline.hip.h
+static void gd_join_open_tickets(gdiet_ctx *ctx);
 
 extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 {
 	if (!ctx) return;
+	gd_join_open_tickets(ctx); // batches still in flight run to their end first: their lanes use this context's pool, arena and streams
 	if (ctx->pool) gd_pool_free(ctx->pool), ctx->pool = nullptr;
 	for (gdiet_ctx *c : ctx->children) gdiet_hip_destroy(c);
 	ctx->children.clear();
@@ -521,12 +524,16 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	if (ctx->parent && !own && bt > arena.cap) GD_HIP(hipEventSynchronize(ctx->parent->arena_ev)); // growing it: the previous user must be done
 	if ((rc = gd_grow(ctx, arena, bt))) {
 		// a context working synchronously after batches were in flight: its idle lanes may still hold private arenas
+		// (a lane that takes its turn in the shared arena reclaims the private arenas of its idle siblings the same way)
 		bool freed = false;
-		if (!ctx->parent && rc == GDIET_E_NOMEM)
+		if (rc == GDIET_E_NOMEM) {
+			gdiet_ctx *owner = ctx->parent ? ctx->parent : ctx;
+			std::lock_guard<std::mutex> guard(owner->async_mu); // async_busy[] belongs to submit / wait
 			for (int i = 0; i < 4; ++i) {
-				gdiet_ctx *c = ctx->async_lane[i];
-				if (c && !ctx->async_busy[i] && c->arena.p) { (void)hipFree(c->arena.p); c->arena.p = nullptr, c->arena.cap = 0, freed = true; }
+				gdiet_ctx *c = owner->async_lane[i];
+				if (c && c != ctx && !owner->async_busy[i] && c->arena.p) { (void)hipFree(c->arena.p); c->arena.p = nullptr, c->arena.cap = 0, freed = true; }
 			}
+		}
 		if (!freed || (rc = gd_grow(ctx, arena, bt))) return rc;
 		ctx->err.clear();
 	}

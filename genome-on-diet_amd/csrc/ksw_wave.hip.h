@@ -3,9 +3,9 @@
 // anti-diagonal written with one coalesced global_store_dwordx4 (1 KiB per wavefront-row).
 // All arithmetic lives in ksw_wave_core.h (shared with the host lock-step emulator); this file is the row loop.
 //
-// Roofline note: per anti-diagonal a wavefront issues ~330 VALU instructions for 1024 cells and
-// stores 1024 B, i.e. ~1 B of HBM write per cell against ~20 lane-ops per cell: the kernel is VALU-issue bound
-// at roughly 0.6x of what the 8 TB/s HBM roofline would allow for the 1 B/cell backtrace.
+// Roofline note: per anti-diagonal a wavefront issues ~310 VALU + ~120 SALU instructions for 1024 cells and
+// stores 1024 B: the kernel is bound by VALU issue (one wave64 instruction per ~4.2 cycles per SIMD, whatever its encoding:
+// profiles/r02_valu_issue.md), at 0.22-0.23 of what the 8 TB/s HBM roofline would allow for the 1 B/cell backtrace.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ksw_common.h"
@@ -32,6 +32,16 @@ __device__ __forceinline__ u32 gdw_seam_byte(const uint8_t *query, int qlen, int
 	typedef const __attribute__((address_space(4))) u32 *gdw_const_u32p;
 	const u32 wd = *(gdw_const_u32p)(a & ~(uintptr_t)3);
 	return (wd >> (8 * (a & 3))) & 0xffu;
+}
+
+// gd_band for wave-uniform arguments, kept on the scalar unit (left to itself the compiler evaluates en0 with v_min3_i32 and two
+// v_readfirstlane_b32: five vector instructions per anti-diagonal)
+__device__ __forceinline__ void gdw_band_uniform(int r, int qlen, int tlen, int w, int &st0, int &en0)
+{
+	int a = r - qlen + 1, b = (r - w + 1) >> 1, c = (r + w) >> 1, t1 = tlen - 1, st, en;
+	asm("s_max_i32 %0, %1, %2\n\ts_max_i32 %0, %0, 0" : "=&s"(st) : "s"(a), "s"(b) : "scc");
+	asm("s_min_i32 %0, %1, %2\n\ts_min_i32 %0, %0, %3" : "=&s"(en) : "s"(t1), "s"(r), "s"(c) : "scc");
+	st0 = st, en0 = en;
 }
 
 __device__ __forceinline__ const uint8_t *gdw_uniform_ptr(const uint8_t *p, int src_lane)
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(256) void ksw_extd2_wave_kernel(const KswTask *__re
 	for (int r = 0; r <= rend; ++r) {
 		WaveRow W;
 		W.r = r;
-		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		gdw_band_uniform(r, qlen, tlen, w, W.st0, W.en0);
 		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
 		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
 		const int advanced = W.st_ > prev_st_;
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *_
 	for (int r = 0; r <= rend; ++r) {
 		WaveRow W;
 		W.r = r;
-		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		gdw_band_uniform(r, qlen, tlen, w, W.st0, W.en0);
 		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
 		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
 		const int advanced = W.st_ > prev_st_;
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave2x64_kernel(const KswTask *
 	for (int r = 0; r <= rend; ++r) {
 		WaveRow W;
 		W.r = r;
-		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		gdw_band_uniform(r, qlen, tlen, w, W.st0, W.en0);
 		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
 		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
 		const int advanced = W.st_ > prev_st_;

@@ -38,11 +38,9 @@ static void gd_pool_free(void *pool) { delete (GdPool *)pool; }
 static GdPool *gd_pool(gdiet_ctx *ctx)
 {
 	gdiet_ctx *owner = ctx->parent ? ctx->parent : ctx; // an async lane works in its parent's pool
-	if (!owner->pool) {
-		static std::mutex create_mu;
-		std::unique_lock<std::mutex> lk(create_mu);
-		if (!owner->pool) owner->pool = new GdPool();
-	}
+	static std::mutex create_mu; // (taken on every call: a handful per batch; a plain pointer must not be double-checked without it)
+	std::lock_guard<std::mutex> lk(create_mu);
+	if (!owner->pool) owner->pool = new GdPool();
 	return (GdPool *)owner->pool;
 }
 
@@ -380,6 +378,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	const int n = B.n;
 	for (int i = 0; i < 6; ++i) ctx->stage_s[i] = 0;
 	if (n == 0) return GDIET_OK;
+	for (int i = 0; i < n; ++i) n_regs[i] = 0, regs[i] = nullptr; // whatever happens below, gdiet_hip_free_regs on these arrays is safe
 	hipStream_t s = ctx->stream;
 	int rc;
 	double t0 = gd_now();
@@ -584,7 +583,10 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		rc = gd_ksw_batch_dev(ctx, nb, (const uint8_t *)ctx->m_q.p, (const uint8_t *)ctx->m_t.p, d_ex, &ks, d_score, d_ncig, (uint32_t *)ctx->m_cig.p, d_coff,
 		                      qoff.data(), toff.data(), bw.data(), sd, coff.data(), ex.data(), ctx->parent ? ctx->parent->arena_ev : nullptr,
 		                      ctx->parent ? &dp_lock : nullptr);
-		if (rc) return rc; // (the lock, if taken, is released by dp_lock's destructor)
+		if (rc) { // kernels of this stage may already be queued in the shared arena: let them finish before the next lane takes its turn
+			(void)hipStreamSynchronize(sd);
+			return rc; // (the lock, if taken, is released by dp_lock's destructor)
+		}
 	mark("d:plan+enqueue");
 		if (ctx->parent) {
 			if (!ctx->own_arena) GD_HIP(hipEventRecord(ctx->parent->arena_ev, sd)); // the backtrack is done by then: the CIGARs sit in this lane's own buffer
@@ -742,6 +744,22 @@ struct gdiet_map_ticket {
 	GdMapOpt O;
 };
 
+// gdiet_hip_destroy with tickets still open: their lane threads are joined (results dropped) before anything is released
+static void gd_join_open_tickets(gdiet_ctx *ctx)
+{
+	std::vector<void *> open;
+	{
+		std::lock_guard<std::mutex> guard(ctx->async_mu);
+		open.swap(ctx->open_tickets);
+	}
+	for (void *p : open) {
+		gdiet_map_ticket *t = (gdiet_map_ticket *)p;
+		if (t->th.joinable()) t->th.join();
+		ctx->async_busy[t->lane] = false;
+		delete t;
+	}
+}
+
 extern "C" int gdiet_hip_set_inflight(gdiet_ctx *ctx, int n)
 {
 	if (!ctx || n < 1 || n > GD_MAX_INFLIGHT) return GDIET_E_PARAM;
@@ -784,6 +802,7 @@ extern "C" int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *ix, const
 	c->lane_threads = c->host_threads = ctx->host_threads; // all lanes draw from the parent's pool
 	ctx->async_busy[l] = true, ctx->async_next++;
 	t->lane = l;
+	ctx->open_tickets.push_back(t);
 	t->th = std::thread([=]() {
 		GdBatchView V = {B->n, B->roff.data(), B->enc.data(), (const uint8_t *)B->d_reads, (const int64_t *)B->d_roff};
 		t->rc = B->n ? gd_map_range(c, ix, t->O, V, n_regs, regs) : GDIET_OK;
@@ -797,6 +816,8 @@ extern "C" int gdiet_hip_map_wait(gdiet_ctx *ctx, gdiet_map_ticket *t)
 	if (!ctx || !t) return GDIET_E_PARAM;
 	if (t->th.joinable()) t->th.join();
 	std::lock_guard<std::mutex> guard(ctx->async_mu);
+	for (size_t i = 0; i < ctx->open_tickets.size(); ++i)
+		if (ctx->open_tickets[i] == t) { ctx->open_tickets.erase(ctx->open_tickets.begin() + i); break; }
 	gdiet_ctx *c = ctx->async_lane[t->lane];
 	const int rc = t->rc;
 	if (rc) ctx->err = c->err;

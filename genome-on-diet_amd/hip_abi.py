@@ -32,7 +32,8 @@ class KswScore(C.Structure):
 
 
 def library_path():
-    return os.path.join(HERE, "libgdiet_hip.so")
+    # GDIET_HIP_LIB: another build of the same library (A/B timing of kernel variants, tools/perf_dp.py); tests and bench.py never set it
+    return os.environ.get("GDIET_HIP_LIB") or os.path.join(HERE, "libgdiet_hip.so")
 
 
 _lib = None

@@ -314,3 +314,46 @@ def test_file_to_sam_with_batches_in_flight(gpu_ctx, pkg, tmp_path):
             assert open(out).read() == "".join(l + "\n" for l in golden_sam("sr"))
     finally:
         m.close()
+
+
+def test_file_to_sam_failure_does_not_hang(gpu_ctx, pkg, tmp_path):
+    """tools/map_file.py when a stage fails (here: the output sink raises on its second write): the call raises instead of hanging,
+    every open ticket has been waited for, and the mapper maps the next file as if nothing had happened"""
+    import sys
+    import threading
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import map_file
+    from fixture_io import SR
+    names, seqs = read_fasta(os.path.join(SR, "ref.fa.gz"))
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset="sr")
+
+    class Sink:
+        def __init__(self):
+            self.n = 0
+
+        def write(self, b):
+            self.n += 1
+            if self.n == 2:
+                raise IOError("disk full")
+            return len(b)
+
+    try:
+        box = {}
+
+        def run():
+            try:
+                map_file.map_file(pkg, m, os.path.join(SR, "sr.fq.gz"), Sink(), 15000, 3, 2)
+                box["r"] = "no error"
+            except IOError as e:
+                box["r"] = str(e)
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(120)
+        assert not th.is_alive(), "map_file hangs after a failed write"
+        assert box.get("r") == "disk full"
+        out = str(tmp_path / "after.sam")
+        with open(out, "wb") as f:
+            n, _ = map_file.map_file(pkg, m, os.path.join(SR, "sr.fq.gz"), f, 45000, 3, 2)
+        assert n == 2000 and open(out).read() == "".join(l + "\n" for l in golden_sam("sr"))
+    finally:
+        m.close()

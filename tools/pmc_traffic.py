@@ -42,6 +42,10 @@ def main():
             if line.startswith("{") and '"roofline"' in line:
                 r = json.loads(line)["roofline"]
                 res["dp_cells_per_launch"], res["algorithmic_bytes_per_launch"] = r["dp_cells_per_launch"], r["algorithmic_bytes_per_launch"]
+                if "dp_cells_all_launches" in r and calls:  # every launch of the process was counted: bytes per DP cell
+                    n_l = max(calls.values())
+                    assert n_l == r["dp_launches"], "the profile saw %d launches, the bench made %d" % (n_l, r["dp_launches"])
+                    res["traffic_bytes_per_cell"] = (tot.get("WRITE_SIZE", 0.0) * 1024 + tot.get("FETCH_SIZE", 0.0) * 1024 * 2) / r["dp_cells_all_launches"]
                 break
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
