@@ -21,6 +21,7 @@
 #include "ksw_generic.hip.h"
 #include "ksw_backtrack.hip.h"
 #include "ksw_wave.hip.h"
+#include "ksw_extz2_exact.hip.h"
 
 struct DevBuf {
 	void *p = nullptr;
@@ -718,6 +719,79 @@ extern "C" int gdiet_hip_ksw_extz2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 	const int rc = gdiet_hip_ksw_extd2_batch(ctx, n, qseq, qoff, tseq, toff, w, nullptr, &s2, score, n_cigar, cigar, cigar_off);
 	ctx->single_affine = false;
 	return rc;
+}
+
+// exact-max mode of ksw_extz2 (flag without APPROX_MAX): ksw_extz2_exact.hip.h
+extern "C" int gdiet_hip_ksw_extz2_batch_ex(gdiet_ctx *ctx, int n, const uint8_t *qseq, const int64_t *qoff, const uint8_t *tseq,
+                                            const int64_t *toff, const int32_t *w, const gdiet_ksw_score_t *sc, int32_t zdrop, int32_t end_bonus,
+                                            gdiet_ksw_extz_t *ez, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	if (n <= 0) return GDIET_OK;
+	if (!qseq || !qoff || !tseq || !toff || !w || !sc || !ez || !n_cigar || !cigar || !cigar_off) { ctx->err = "NULL argument"; return GDIET_E_PARAM; }
+	if (sc->flag & ~GD_EZ_EXTZ_ONLY) {
+		ctx->err = "gdiet_hip_ksw_extz2_batch_ex takes flag 0 or KSW_EZ_EXTZ_ONLY (exact maximum); APPROX_MAX: gdiet_hip_ksw_extz2_batch";
+		return GDIET_E_PARAM;
+	}
+	static_assert(sizeof(gdiet_ksw_extz_t) == sizeof(GdExtzOut), "public and kernel record differ");
+	(void)hipSetDevice(ctx->device);
+	hipStream_t s = ctx->stream;
+	KswzConst K;
+	K.q = sc->q, K.e = sc->e, K.sc_mch = sc->match, K.sc_mis = sc->mismatch, K.sc_N = sc->sc_ambi == 0 ? -sc->e : sc->sc_ambi;
+	K.zdrop = zdrop, K.end_bonus = end_bonus, K.flag = sc->flag;
+	{ // :88-90: the reference returns without aligning
+		const int min_sc = std::min<int>(std::min<int>(sc->mismatch, sc->match), std::min<int>(sc->sc_ambi, 0));
+		if (-min_sc > 2 * (K.q + K.e)) { ctx->err = "-min_sc > 2*(q+e): the reference returns without aligning"; return GDIET_E_PARAM; }
+	}
+	int rc;
+	if ((rc = gd_host_grow(ctx, ctx->h_tasks, sizeof(KswTask) * (size_t)n))) return rc;
+	KswTask *h_tasks = (KswTask *)ctx->h_tasks.p;
+	size_t bt = 0;
+	int max_cap = 0;
+	for (int i = 0; i < n; ++i) {
+		KswTask &T = h_tasks[i];
+		T.qoff = qoff[i], T.toff = toff[i], T.qlen = (int)(qoff[i + 1] - qoff[i]), T.tlen = (int)(toff[i + 1] - toff[i]), T.w = w[i];
+		if (T.qlen <= 0 || T.tlen <= 0) { ctx->err = "empty sequence in batch (the reference returns without aligning)"; return GDIET_E_PARAM; }
+		T.cig_off = cigar_off[i], T.cig_cap = (int32_t)std::min<int64_t>(cigar_off[i + 1] - cigar_off[i], 0x7fffffff);
+		T.exact_score = GD_NEG_INF, T.kind = GD_KIND_GENERIC, T.pad = 0;
+		T.row_bytes = gd_ncol16(T.qlen, T.tlen, T.w) * 16;
+		T.bt_off = (int64_t)bt;
+		bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
+		max_cap = std::max(max_cap, gd_generic_cap(T.qlen, T.tlen, T.w));
+	}
+	const size_t lds = (size_t)max_cap * 9;
+	if (lds > 160 * 1024 - 1024) { ctx->err = "band wider than the LDS window of the exact-maximum kernel"; return GDIET_E_PARAM; }
+	const size_t qb = (size_t)qoff[n], tb = (size_t)toff[n], cb = (size_t)cigar_off[n];
+	if ((rc = gd_grow(ctx, ctx->arena, bt))) return rc;
+	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->status, sizeof(int32_t) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->qseq, qb + 64))) return rc;
+	if ((rc = gd_grow(ctx, ctx->tseq, tb + 64))) return rc;
+	if ((rc = gd_grow(ctx, ctx->score, sizeof(int32_t) * 3 * (size_t)n + sizeof(GdExtzOut) * (size_t)n))) return rc; // score | start (2n) | ez
+	if ((rc = gd_grow(ctx, ctx->ncig, sizeof(int32_t) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->cigar, sizeof(uint32_t) * (cb + 1)))) return rc;
+	int32_t *d_score = (int32_t *)ctx->score.p, *d_start = d_score + n;
+	GdExtzOut *d_ez = (GdExtzOut *)(d_start + 2 * (size_t)n);
+	GD_HIP(hipMemcpyAsync(ctx->qseq.p, qseq, qb, hipMemcpyHostToDevice, s));
+	GD_HIP(hipMemcpyAsync(ctx->tseq.p, tseq, tb, hipMemcpyHostToDevice, s));
+	GD_HIP(hipMemcpyAsync(ctx->tasks.p, h_tasks, sizeof(KswTask) * n, hipMemcpyHostToDevice, s));
+	if (lds > 64 * 1024) GD_HIP(hipFuncSetAttribute((const void *)ksw_extz2_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	ctx->last_mask = 2, ctx->last_was_async = false, ctx->last_split = 0;
+	GD_HIP(hipEventRecord(ctx->ev[0], s));
+	hipLaunchKernelGGL(ksw_extz2_exact_kernel, dim3(n), dim3(64), lds, s, (const KswTask *)ctx->tasks.p, n, (const uint8_t *)ctx->qseq.p, (const uint8_t *)ctx->tseq.p,
+	                   (uint8_t *)ctx->arena.p, (int32_t *)ctx->status.p, d_score, d_ez, d_start, K, max_cap);
+	GD_HIP(hipEventRecord(ctx->ev[1], s));
+	hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((n + 63) / 64), dim3(64), 0, s, (const KswTask *)ctx->tasks.p, n, (const uint8_t *)ctx->arena.p,
+	                   (const int32_t *)ctx->status.p, d_score, (int32_t *)ctx->ncig.p, (uint32_t *)ctx->cigar.p, 0, (const int32_t *)nullptr, (const int32_t *)d_start);
+	GD_HIP(hipEventRecord(ctx->ev[2], s));
+	GD_HIP(hipMemcpyAsync(ez, d_ez, sizeof(GdExtzOut) * n, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipMemcpyAsync(n_cigar, ctx->ncig.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipMemcpyAsync(cigar, ctx->cigar.p, sizeof(uint32_t) * cb, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipStreamSynchronize(s));
+	GD_HIP(hipGetLastError());
+	for (int i = 0; i < n; ++i)
+		if (n_cigar[i] > cigar_off[i + 1] - cigar_off[i]) { ctx->err = "CIGAR of alignment " + std::to_string(i) + " needs " + std::to_string(n_cigar[i]) + " ops"; return GDIET_E_CIGAR_CAP; }
+	return GDIET_OK;
 }
 
 #include "map_pipeline.hip.h"

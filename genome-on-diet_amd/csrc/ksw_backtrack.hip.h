@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
                                                            const uint8_t *__restrict__ bt,
                                                            const int32_t *__restrict__ status,
                                                            int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
-                                                           uint32_t *__restrict__ cigar, int spread, const int32_t *__restrict__ task_ids)
+                                                           uint32_t *__restrict__ cigar, int spread, const int32_t *__restrict__ task_ids,
+                                                           const int32_t *__restrict__ start = nullptr /* (i0, j0) per task; default: the last cell */)
 {
 	// spread = 1: one alignment per WAVEFRONT (lane 0 walks, the other lanes idle).  Kept for experiments only: it measured 2x
 	// SLOWER than one walk per thread, whose 64 x 16 prefetched loads per wavefront hide the latency better.
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 	const uint8_t *p = bt + T.bt_off;
 	uint32_t *cg = cigar + T.cig_off;
 	const int cap = T.cig_cap;
-	int nc = 0, i = tlen - 1, j = qlen - 1, state = 0;
+	int nc = 0, i = start ? start[2 * tid] : tlen - 1, j = start ? start[2 * tid + 1] : qlen - 1, state = 0;
 	uint32_t last = 0; // the op run being extended (kept in a register, flushed on change)
 	int have = 0;
 #define GD_PUSH(op_, len_)                                                       \

@@ -69,6 +69,7 @@ def load_library():
     lib.gdiet_hip_ksw_extd2_batch_dev.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(KswScore),
                                                   vp, vp, vp, vp, i64p, i64p, i32p, vp]
     lib.gdiet_hip_ksw_extz2_batch.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, C.POINTER(KswScore), i32p, i32p, u32p, i64p]
+    lib.gdiet_hip_ksw_extz2_batch_ex.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, C.POINTER(KswScore), C.c_int32, C.c_int32, i32p, i32p, u32p, i64p]
     _lib = lib
     return lib
 
@@ -177,6 +178,24 @@ class Context:
                                                 _ptr(nc, C.c_int32), _ptr(cg, C.c_uint32), _ptr(coff, C.c_int64))
         self._check(rc)
         return sc, [cg[coff[i]:coff[i] + nc[i]].copy() for i in range(n)]
+
+    EXTZ_FIELDS = ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "reach_end")
+
+    def ksw_extz2_batch_ex(self, queries, targets, w, score, zdrop=-1, end_bonus=0):
+        """exact-maximum mode of ksw_extz2_sse (score.flag = 0 or 0x40 = KSW_EZ_EXTZ_ONLY): returns (list of dicts with the scalars of
+        ksw_extz_t, list of uint32 CIGAR arrays)"""
+        n = len(queries)
+        qbuf, qoff = pack(queries)
+        tbuf, toff = pack(targets)
+        w = np.ascontiguousarray(np.broadcast_to(np.asarray(w, np.int32), (n,)))
+        coff = np.zeros(n + 1, np.int64)
+        coff[1:] = np.cumsum([len(q) + len(t) for q, t in zip(queries, targets)])
+        ez, nc, cg = np.zeros((n, 10), np.int32), np.zeros(n, np.int32), np.zeros(int(coff[-1]) + 1, np.uint32)
+        rc = self.lib.gdiet_hip_ksw_extz2_batch_ex(self._h, n, _ptr(qbuf, C.c_uint8), _ptr(qoff, C.c_int64), _ptr(tbuf, C.c_uint8),
+                                                   _ptr(toff, C.c_int64), _ptr(w, C.c_int32), C.byref(score), int(zdrop), int(end_bonus),
+                                                   _ptr(ez, C.c_int32), _ptr(nc, C.c_int32), _ptr(cg, C.c_uint32), _ptr(coff, C.c_int64))
+        self._check(rc)
+        return [dict(zip(self.EXTZ_FIELDS, (int(v) for v in ez[i]))) for i in range(n)], [cg[coff[i]:coff[i] + nc[i]].copy() for i in range(n)]
 
     def ksw_extd2_batch_dev(self, n, d_qseq, d_tseq, d_exact, score, d_score, d_ncig, d_cigar, d_cigoff,
                             h_qoff, h_toff, h_w, stream=0):

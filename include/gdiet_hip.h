@@ -96,7 +96,8 @@ int gdiet_hip_ksw_extd2_batch_dev(gdiet_ctx *ctx, int n,
 /* ---- K3: batched banded SINGLE-affine global alignment -------------------------------------------------------------
  * Replaces ksw_extz2_sse + ksw_backtrack (SR/ksw2_extz2_sse.c:31-312, SR/ksw2.h:62; BASELINE config 2; not called by the live
  * mapping path).  Same batch layout and outputs as gdiet_hip_ksw_extd2_batch; sc->q / sc->e are the gap costs, sc->q2 / sc->e2
- * are ignored, sc->flag must be GDIET_EZ_APPROX_MAX (the only mode GDiet ever passes); sequence bytes must be 0..4 (the one
+ * are ignored, sc->flag must be GDIET_EZ_APPROX_MAX (the only mode GDiet ever passes; the exact-maximum mode is
+ * gdiet_hip_ksw_extz2_batch_ex below); sequence bytes must be 0..4 (the one
  * out-of-alphabet byte GDiet produces, 7 for a reverse-complemented N, only ever reaches ksw_extd2).  Implementation note: in
  * that mode ksw_extz2(q,e) and ksw_extd2(q,e,q,e) visit identical cells with identical values (the unsigned bias of extz2 is a
  * re-labelling, and a second gap model equal to the first can never win the priority chain), so the register-resident kernels
@@ -107,6 +108,21 @@ int gdiet_hip_ksw_extz2_batch(gdiet_ctx *ctx, int n,
                               const uint8_t *tseq, const int64_t *toff,
                               const int32_t *w, const gdiet_ksw_score_t *sc,
                               int32_t *score, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off);
+
+/* K3, exact-maximum mode: ksw_extz2_sse called WITHOUT KSW_EZ_APPROX_MAX (SR/ksw2_extz2_sse.c:226-268: the per-cell H array, the
+ * row maximum with z-drop, SR/ksw2.h:172-188), the second mode SURVEY 8d names for BASELINE config 2.  sc->flag = 0 or
+ * GDIET_EZ_EXTZ_ONLY (SR/ksw2.h:15); zdrop / end_bonus as the reference's arguments (zdrop < 0: no z-drop).  ez[i] receives every
+ * scalar of ksw_extz_t (SR/ksw2.h:31-40); the CIGAR is the walk from the last cell, from (mqe_t, qlen-1) when EXTZ_ONLY reaches
+ * the query end, or from (max_t, max_q) after a z-drop, exactly as :296-305.  One wavefront per alignment, state in LDS. */
+#define GDIET_EZ_EXTZ_ONLY 0x40
+typedef struct {
+	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end;
+} gdiet_ksw_extz_t;
+int gdiet_hip_ksw_extz2_batch_ex(gdiet_ctx *ctx, int n,
+                                 const uint8_t *qseq, const int64_t *qoff,
+                                 const uint8_t *tseq, const int64_t *toff,
+                                 const int32_t *w, const gdiet_ksw_score_t *sc, int32_t zdrop, int32_t end_bonus,
+                                 gdiet_ksw_extz_t *ez, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off);
 
 /* make sure the context owns at least `bytes` of device workspace (backtrace arena); returns GDIET_E_NOMEM
  * if the device cannot provide it.  gdiet_hip_ksw_extd2_batch() grows the arena by itself. */

@@ -154,6 +154,44 @@ def main():
             n_bad_em += 1
         if i < 60:
             em.append((q, t, gdo.ref_exact_match(ref, q, t, mat)))
+    # exact-maximum mode of ksw_extz2 (flag 0 / KSW_EZ_EXTZ_ONLY, with and without z-drop): what gdiet_hip_ksw_extz2_batch_ex answers
+    n_bad_exact = 0
+    gold_exact = []
+    rng = np.random.default_rng(args.seed + 1000)  # (a stream of its own: these vectors do not depend on --fuzz)
+    for i in range(1200 if args.fuzz >= 1000 else 300):
+        preset = ("sr", "hifi", "ont")[i % 3]
+        a, b, go, ge, _, _ = gdo.PRESETS[preset]
+        mat = gdo.score_matrix(a, b)
+        tlen = int(rng.integers(20, 420))
+        t = rng.integers(0, 4, size=tlen, dtype=np.uint8)
+        if i % 9 == 0:
+            t[rng.integers(0, tlen, size=max(1, tlen // 50))] = 4
+        q = t.copy()
+        m = rng.random(tlen) < (0.02 if i % 2 else 0.08)
+        q[m] = (q[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+        q = q[rng.random(len(q)) >= 0.01]
+        if i % 4 == 1 and len(q) > 60:  # a long indel or an unrelated tail: z-drop / a maximum inside the matrix
+            cut = int(rng.integers(20, len(q) - 20))
+            q = np.concatenate([q[:cut], rng.integers(0, 4, size=int(rng.integers(5, 80)), dtype=np.uint8), q[cut:]]) if i % 8 == 1 else \
+                np.concatenate([q[:cut], rng.integers(0, 4, size=len(q) - cut, dtype=np.uint8)])
+        if len(q) == 0:
+            q = t[:1].copy()
+        w = int(rng.integers(8, 200)) if i % 5 else -1
+        zdrop = (-1, 20, 100, 400)[(i // 3) % 4]
+        end_bonus = (0, 5)[(i // 12) % 2]
+        flag = (0, gdo.EZ_EXTZ_ONLY)[(i // 24) % 2]
+        oz = gdo.oracle_extz2(ora, q, t, mat, go, ge, w, zdrop, end_bonus, flag)
+        rz = gdo.ref_extz2(ref, q, t, mat, go, ge, w, zdrop, end_bonus, flag)
+        keys = ("score", "zdropped", "max", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "reach_end")
+        if not gdo.same(oz, rz, keys):
+            n_bad_exact += 1
+            if n_bad_exact <= 5:
+                print("MISMATCH extz2 exact mode oracle vs SSE", i, len(q), len(t), preset, w, flag, zdrop, {k: (oz[k], rz[k]) for k in keys if oz[k] != rz[k]})
+        if i < 300:
+            gold_exact.append((q, t, preset, w, zdrop, end_bonus, flag, rz))
+    n_bad_sse += n_bad_exact
+    print("extz2 exact-maximum mode: pairs=%d oracle_vs_sse_mismatch=%d (z-dropped in %d of the %d golden pairs)"
+          % (1200 if args.fuzz >= 1000 else 300, n_bad_exact, sum(1 for g in gold_exact if g[7]["zdropped"]), len(gold_exact)))
     print("pairs=%d oracle_vs_sse_mismatch=%d oracle_vs_avx512_mismatch=%d sse_vs_avx512_differ_on_byte7_inputs=%d exact_match_mismatch=%d"
           % (args.fuzz, n_bad_sse, n_bad_avx, n_sse_vs_avx, n_bad_em))
 
@@ -182,6 +220,14 @@ def main():
                                              "reach_end")] for g in gold_avx], np.int64)
         np.savez_compressed(os.path.join(GOLDEN, "ksw2_extd2_avx512.npz"), q=qs7, qo=qo7, t=ts7, to=to7, params=params7,
                             cigar_bytes=cg7, cigar_off=co7, scalars=scal7)
+        qsx, qox = pack([g[0] for g in gold_exact])
+        tsx, tox = pack([g[1] for g in gold_exact])
+        paramsx = np.array([[("sr", "hifi", "ont").index(g[2]), g[3], g[4], g[5], g[6]] for g in gold_exact], np.int32)
+        cgx, cox = pack([g[7]["cigar"].view(np.uint8) for g in gold_exact])
+        scalx = np.array([[g[7][f] for f in ("score", "zdropped", "max", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q",
+                                             "reach_end")] for g in gold_exact], np.int64)
+        np.savez_compressed(os.path.join(GOLDEN, "ksw2_extz2_exact.npz"), q=qsx, qo=qox, t=tsx, to=tox, params=paramsx,
+                            cigar_bytes=cgx, cigar_off=cox, scalars=scalx)
         eq, eqo = pack([e[0] for e in em])
         et, eto = pack([e[1] for e in em])
         np.savez_compressed(os.path.join(GOLDEN, "exact_match.npz"), q=eq, qo=eqo, t=et, to=eto,

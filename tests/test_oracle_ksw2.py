@@ -26,6 +26,20 @@ def test_extz2_oracle_matches_reference_golden(oracle):
         assert np.array_equal(o["cigar"], c["cigar"])
 
 
+def test_extz2_exact_mode_oracle_matches_reference_golden(oracle):
+    """flag 0 / KSW_EZ_EXTZ_ONLY with and without z-drop (tests/golden/ksw2_extz2_exact.npz): the oracle the exact-maximum GPU
+    kernel is fuzzed against reproduces ksw_extz2_sse's scalars and CIGARs"""
+    gdo, lib = oracle
+    cases = load_ksw("ksw2_extz2_exact")
+    assert len(cases) >= 300 and sum(c["zdropped"] for c in cases) >= 20
+    for c in cases:
+        a, b, q, e, q2, e2 = gdo.PRESETS[c["preset"]]
+        o = gdo.oracle_extz2(lib, c["q"], c["t"], gdo.score_matrix(a, b), q, e, c["w"], c["zdrop"], c["end_bonus"], c["flag"])
+        for k in SCALARS:
+            assert o[k] == c[k], (k, o[k], c[k])
+        assert np.array_equal(o["cigar"], c["cigar"])
+
+
 def test_exact_match_oracle_matches_reference_golden(oracle):
     gdo, lib = oracle
     cases = load_exact()
