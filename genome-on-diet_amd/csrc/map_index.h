@@ -259,6 +259,71 @@ static inline bool gd_index_read_mmi(GdIndex &h, const char *path, const GdPatte
 
 // Writes an index the reference's mm_idx_load accepts (same records as mm_idx_dump; the order of the keys inside a bucket is
 // khash-internal in the reference's files and carries no meaning: mm_idx_load re-inserts them one by one).
+// khash's slot placement (LR/khash.h:199-330), emulated for the one call sequence the index builder makes: kh_init, kh_resize(n_keys),
+// then kh_put of every key of the bucket in ascending order (LR/index.c:216-264, worker_post).  mm_idx_dump writes a bucket's entries
+// in SLOT order (LR/index.c:497-516), so a byte-identical .mmi needs the slots, not just the set of keys.  hash = key >> 1 (idx_hash,
+// LR/index.c:20), truncated to 32 bits; linear-quadratic probing i += ++step; rehash with the kick-out process of kh_resize.
+struct GdKhEmu {
+	uint32_t n_buckets = 0, size = 0, n_occupied = 0, upper_bound = 0;
+	std::vector<uint8_t> flag; // 2 = empty, 1 = deleted, 0 = live (khash packs these two bits sixteen to a word)
+	std::vector<uint64_t> keys;
+	std::vector<uint32_t> vals; // index of the entry
+	static uint32_t roundup32(uint32_t x) { --x, x |= x >> 1, x |= x >> 2, x |= x >> 4, x |= x >> 8, x |= x >> 16; return ++x; }
+	void resize(uint32_t new_n)
+	{
+		new_n = roundup32(new_n);
+		if (new_n < 4) new_n = 4;
+		if (size >= (uint32_t)(new_n * 0.77 + 0.5)) return; // requested size is too small
+		std::vector<uint8_t> nf(new_n, 2);
+		if (n_buckets < new_n) keys.resize(new_n), vals.resize(new_n);
+		for (uint32_t j = 0; j != n_buckets; ++j) {
+			if (flag[j] != 0) continue;
+			uint64_t key = keys[j];
+			uint32_t val = vals[j];
+			const uint32_t new_mask = new_n - 1;
+			flag[j] = 1;
+			for (;;) { // kick-out process
+				uint32_t step = 0, i = (uint32_t)(key >> 1) & new_mask;
+				while (nf[i] != 2) i = (i + (++step)) & new_mask;
+				nf[i] = 0;
+				if (i < n_buckets && flag[i] == 0) { // kick out the existing element
+					std::swap(keys[i], key), std::swap(vals[i], val);
+					flag[i] = 1;
+				} else {
+					keys[i] = key, vals[i] = val;
+					break;
+				}
+			}
+		}
+		if (n_buckets > new_n) keys.resize(new_n), vals.resize(new_n);
+		flag.swap(nf);
+		n_buckets = new_n, n_occupied = size, upper_bound = (uint32_t)(n_buckets * 0.77 + 0.5);
+	}
+	void put(uint64_t key, uint32_t val) // keys are distinct (asserted by the reference: `absent`)
+	{
+		if (n_occupied >= upper_bound) {
+			if (n_buckets > (size << 1)) resize(n_buckets - 1);
+			else resize(n_buckets + 1);
+		}
+		const uint32_t mask = n_buckets - 1;
+		uint32_t step = 0, i = (uint32_t)(key >> 1) & mask, x = n_buckets, site = n_buckets;
+		if (flag[i] == 2) x = i;
+		else {
+			const uint32_t last = i;
+			while (flag[i] != 2 && (flag[i] == 1 || keys[i] >> 1 != key >> 1)) {
+				if (flag[i] == 1) site = i;
+				i = (i + (++step)) & mask;
+				if (i == last) { x = site; break; }
+			}
+			if (x == n_buckets) x = (flag[i] == 2 && site != n_buckets) ? site : i;
+		}
+		if (flag[x] == 2) keys[x] = key, vals[x] = val, flag[x] = 0, ++size, ++n_occupied;
+		else if (flag[x] == 1) keys[x] = key, vals[x] = val, flag[x] = 0, ++size;
+	}
+};
+
+// mm_idx_dump (LR/index.c:480-517), byte for byte: per bucket the position array p[] in the order worker_post fills it (keys
+// ascending, each list ascending), then the hash table's live slots in slot order
 static inline bool gd_index_write_mmi(const GdIndex &h, const char *path, int bucket_bits, std::string &err)
 {
 	FILE *fp = fopen(path, "wb");
@@ -275,17 +340,24 @@ static inline bool gd_index_write_mmi(const GdIndex &h, const char *path, int bu
 	std::vector<std::vector<uint32_t>> slots(1u << b); // table slots by bucket (low b bits of the minimizer)
 	for (size_t sl = 0; sl < h.tkey.size(); ++sl)
 		if (h.tkey[sl] != UINT64_MAX) slots[h.tkey[sl] & ((1u << b) - 1)].push_back((uint32_t)sl);
-	std::vector<uint64_t> p, kv;
+	std::vector<uint64_t> p, kv, ekey, eval;
 	for (uint32_t bi = 0; bi < (1u << b); ++bi) {
-		p.clear(), kv.clear();
-		for (uint32_t sl : slots[bi]) {
+		std::vector<uint32_t> &sl_of = slots[bi];
+		std::sort(sl_of.begin(), sl_of.end(), [&](uint32_t a, uint32_t c) { return h.tkey[a] < h.tkey[c]; }); // radix_sort_128x: ascending minimizer
+		p.clear(), kv.clear(), ekey.clear(), eval.clear();
+		GdKhEmu kh;
+		if (!sl_of.empty()) kh.resize((uint32_t)sl_of.size());
+		for (uint32_t sl : sl_of) {
 			const uint64_t st = h.tval[sl] >> 32, c = (uint32_t)h.tval[sl], key = h.tkey[sl] >> b << 1;
-			if (c == 1) kv.push_back(key | 1), kv.push_back(h.pos[st]);
+			kh.put(key, (uint32_t)ekey.size());
+			if (c == 1) ekey.push_back(key | 1), eval.push_back(h.pos[st]);
 			else {
-				kv.push_back(key), kv.push_back((uint64_t)p.size() << 32 | c);
+				ekey.push_back(key), eval.push_back((uint64_t)p.size() << 32 | c);
 				p.insert(p.end(), h.pos.begin() + st, h.pos.begin() + st + c);
 			}
 		}
+		for (uint32_t k = 0; k < kh.n_buckets; ++k)
+			if (kh.flag[k] == 0) kv.push_back(ekey[kh.vals[k]]), kv.push_back(eval[kh.vals[k]]);
 		const int32_t n = (int32_t)p.size();
 		const uint32_t size = (uint32_t)(kv.size() / 2);
 		fwrite(&n, 4, 1, fp), fwrite(p.data(), 8, p.size(), fp), fwrite(&size, 4, 1, fp), fwrite(kv.data(), 8, kv.size(), fp);

@@ -175,9 +175,9 @@ int gdiet_hip_index_export(const gdiet_index *idx, uint64_t *n_keys, uint64_t *n
 /* Read an .mmi file written by the reference (mm_idx_dump, LR/index.c:480-517; `GDiet -d`) and upload it.  The file does not store
  * the pattern, so -Z / -W are given again, exactly as on the reference's command line. */
 int gdiet_hip_index_load_mmi(gdiet_ctx *ctx, gdiet_index **idx, const char *path, const char *pattern, int pattern_len);
-/* Write an .mmi file that the reference's mm_idx_load (LR/index.c:519-571) accepts: the same records as mm_idx_dump; only the order
- * of the keys inside a bucket differs from a file written by the reference (it is khash-internal there and carries no meaning).
- * bucket_bits = mm_idxopt_t::bucket_bits (14 by default). */
+/* Write the .mmi file mm_idx_dump (LR/index.c:480-517) writes for this index, byte for byte: the position arrays in the order
+ * worker_post fills them and every bucket's entries in the slot order of the reference's khash table (its resize / put sequence is
+ * emulated: LR/index.c:216-264, LR/khash.h:199-330).  bucket_bits = mm_idxopt_t::bucket_bits (14 by default). */
 int gdiet_hip_index_dump_mmi(gdiet_ctx *ctx, const gdiet_index *idx, const char *path, int bucket_bits);
 void gdiet_hip_index_destroy(gdiet_ctx *ctx, gdiet_index *idx);
 /* mm_idx_cal_max_occ (LR/index.c:190-210) */

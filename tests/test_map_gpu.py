@@ -149,6 +149,15 @@ def test_mmi_index_files(gpu_ctx, pkg, tmp_path):
             m2.close()
     finally:
         m.close()
+    # the index built on the DEVICE from the FASTA sequences, dumped: the very bytes `GDiet_avx -ax sr ... -d` wrote (mm_idx_dump, khash
+    # slot order included)
+    m3 = pkg.Mapper(gpu_ctx, names, seqs, preset="sr")
+    try:
+        built = str(tmp_path / "built.mmi")
+        m3.dump_mmi(built)
+        assert open(built, "rb").read() == open(theirs, "rb").read()
+    finally:
+        m3.close()
     with pytest.raises(pkg.GdietError):
         pkg.Mapper.from_mmi(gpu_ctx, os.path.join(SR, "sr.cmd"), names, [len(s) for s in seqs], preset="sr")  # not an index file
 

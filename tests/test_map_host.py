@@ -94,7 +94,7 @@ def test_sr_host_path_matches_reference_binary_on_fresh_reads(host_driver, tmp_p
 def test_mmi_files_are_exchangeable_with_the_reference(host_driver, tmp_path, kind):
     """the .mmi reader / writer behind gdiet_hip_index_load_mmi / _dump_mmi (map_index.h): (1) an index file written by the
     reference (`GDiet_avx -d`) gives the golden SAM through our path; (2) an index file written by us is accepted by the
-    reference and gives the golden SAM through ITS path"""
+    reference and gives the golden SAM through ITS path -- and is the very file `GDiet_avx -d` writes, byte for byte"""
     variant = "sr" if kind == "sr" else "lr"
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "gdiet_%s_avx" % variant)
     if not os.path.exists(ref_bin):
@@ -113,6 +113,7 @@ def test_mmi_files_are_exchangeable_with_the_reference(host_driver, tmp_path, ki
     got = subprocess.run([exe] + cmd + ["--mmi=" + theirs, ref_fa, fq], capture_output=True, text=True, check=True).stdout.rstrip("\n").split("\n")
     assert got == want
     subprocess.run([exe] + cmd + ["--dump-mmi=" + ours, ref_fa, fq], capture_output=True, check=True)
+    assert open(ours, "rb").read() == open(theirs, "rb").read()  # byte-identical to mm_idx_dump, khash slot order included
     back = subprocess.run([ref_bin, "-t", "4"] + cmd + [ours, fq], capture_output=True, text=True, check=True).stdout
     assert [l for l in back.rstrip("\n").split("\n") if not l.startswith("@")] == want
 
