@@ -47,13 +47,14 @@ struct gdiet_ctx {
 	int wide_two_waves = -1;           // GDIET_WIDE_TWO_WAVES: 1 / 0 force the two-wavefront / two-blocks-per-lane kernel for wide bands, default by count
 	int vote_wave = 1;                 // GDIET_VOTE_WAVE=0: the sequential vote kernel for long reads too
 	int index_on_device = 1;           // GDIET_INDEX_BUILD=host: gdiet_hip_index_build sketches and sorts on host threads instead
+	int post_on_device = 1;            // GDIET_POST=host: mm_fix_cigar / mm_update_extra on host threads instead of map_post_kernel
 	int fuse_bt = 1;                   // GDIET_FUSE_BT=0: the 64-lane kernel leaves the backtrack to the separate kernel
 	bool single_affine = false;        // set for the duration of a gdiet_hip_ksw_extz2_batch call: single-affine kernel variants
 	std::vector<int32_t> h_ids;
 	// per-read mapping path (map_pipeline.hip.h)
-	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack;
+	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack, m_post;
 	std::vector<uint8_t> h_vo;  // host copy of the vote records' heads, kept between batches
-	DevBuf h_boxes, h_cand, h_tasks, h_seedout, h_res, h_cig; // HOST buffers kept between batches (gd_host_grow): the per-batch tables of a
+	DevBuf h_boxes, h_cand, h_tasks, h_seedout, h_res, h_cig, h_post; // HOST buffers kept between batches (gd_host_grow): the per-batch tables of a
 	                                                           // short-read batch are tens of MB each, and allocated fresh they cost page faults
 	int host_threads = 8;
 	int lane_threads = 8;              // host threads this lane may use inside gd_map_range
@@ -197,6 +198,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (vw) ctx->vote_wave = atoi(vw) != 0;
 		const char *ib = getenv("GDIET_INDEX_BUILD");
 		if (ib) ctx->index_on_device = strcmp(ib, "host") != 0;
+		const char *po = getenv("GDIET_POST");
+		if (po) ctx->post_on_device = strcmp(po, "host") != 0;
 		const char *fb = getenv("GDIET_FUSE_BT");
 		if (fb) ctx->fuse_bt = atoi(fb) != 0;
 		const char *ds = getenv("GDIET_DP_SPLIT");
@@ -224,10 +227,10 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar,
 	                  &ctx->m_sc, &ctx->m_mv, &ctx->m_u64, &ctx->m_seed, &ctx->m_seedout, &ctx->m_voteout, &ctx->m_hitoff, &ctx->m_hits,
-	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack};
+	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post};
 	for (DevBuf *b : bufs)
 		if (b->p) (void)hipFree(b->p);
-	DevBuf *hosts[] = {&ctx->h_boxes, &ctx->h_cand, &ctx->h_tasks, &ctx->h_seedout, &ctx->h_res, &ctx->h_cig};
+	DevBuf *hosts[] = {&ctx->h_boxes, &ctx->h_cand, &ctx->h_tasks, &ctx->h_seedout, &ctx->h_res, &ctx->h_cig, &ctx->h_post};
 	for (DevBuf *b : hosts) free(b->p);
 	for (int i = 0; i < 4; ++i)
 		if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include "map_stages.h"
+#include "map_post.h"
 
 #define GD_F_NO_PRINT_2ND 0x4000
 #define GD_F_SR 0x1000
@@ -190,110 +191,26 @@ static inline void gd_lr_link_and_boxes(std::vector<GdCand> &C, const GdMapOpt &
 	}
 }
 
-// ---- P1: mm_fix_cigar + mm_update_extra, LR/align.c:93-172,259-318 -------------------------------------------------------
-static inline float gd_mg_log2(float x) // LR/mmpriv.h:146-157
-{
-	union { float f; uint32_t i; } z = {x};
-	float log_2 = (float)(((z.i >> 23) & 255) - 128);
-	z.i &= ~(255u << 23);
-	z.i += 127u << 23;
-	log_2 += (-0.34484843f * z.f + 2.02466578f) * z.f - 0.67487759f;
-	return log_2;
-}
+// ---- P1: mm_fix_cigar + mm_update_extra, LR/align.c:93-172,259-318: the arithmetic lives in map_post.h (shared with the device
+// kernel); here only the record bookkeeping
+static inline float gd_mg_log2(float x) { return gdp_mg_log2(x); }
 
-static inline void gd_fix_cigar(GdReg &r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
+// a record takes over what P1 computed for its alignment (on the host just now, or on the device right behind the backtrack)
+static inline void gd_apply_post(GdReg &r, const GdPostOut &P)
 {
-	std::vector<uint32_t> &cg = r.cigar;
-	int32_t toff = 0, qoff = 0, to_shrink = 0;
-	uint32_t k, n = (uint32_t)cg.size();
-	*qshift = *tshift = 0;
-	if (n <= 1) return;
-	for (k = 0; k < n; ++k) { // indel left alignment
-		const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
-		if (len == 0) to_shrink = 1;
-		if (op == 0) toff += len, qoff += len;
-		else if (op == 1 || op == 2) {
-			if (k > 0 && k < n - 1 && (cg[k - 1] & 0xf) == 0 && (cg[k + 1] & 0xf) == 0) {
-				int l, prev_len = (int)(cg[k - 1] >> 4);
-				if (op == 1) { for (l = 0; l < prev_len; ++l) if (qseq[qoff - 1 - l] != qseq[qoff + len - 1 - l]) break; }
-				else { for (l = 0; l < prev_len; ++l) if (tseq[toff - 1 - l] != tseq[toff + len - 1 - l]) break; }
-				if (l > 0) cg[k - 1] -= (uint32_t)l << 4, cg[k + 1] += (uint32_t)l << 4, qoff -= l, toff -= l;
-				if (l == prev_len) to_shrink = 1;
-			}
-			if (op == 1) qoff += len; else toff += len;
-		} else if (op == 3) toff += len;
-	}
-	for (k = 0; k + 2 < n; ++k) { // fix CIGAR like 5I6D7I   (k < n_cigar - 2 with unsigned n_cigar >= 2)
-		if ((cg[k] & 0xf) > 0 && (cg[k] & 0xf) + (cg[k + 1] & 0xf) == 3) {
-			uint32_t l, s[3] = {0, 0, 0};
-			for (l = k; l < n; ++l) {
-				const uint32_t op = cg[l] & 0xf;
-				if (op == 1 || op == 2 || cg[l] >> 4 == 0) s[op] += cg[l] >> 4;
-				else break;
-			}
-			if (s[1] > 0 && s[2] > 0 && l - k > 2) {
-				cg[k] = s[1] << 4 | 1, cg[k + 1] = s[2] << 4 | 2;
-				for (k += 2; k < l; ++k) cg[k] &= 0xf;
-				to_shrink = 1;
-			}
-			k = l;
-		}
-	}
-	if (to_shrink) {
-		uint32_t l = 0;
-		for (k = 0; k < n; ++k) if (cg[k] >> 4 != 0) cg[l++] = cg[k];
-		n = l;
-		for (k = l = 0; k < n; ++k)
-			if (k == n - 1 || (cg[k] & 0xf) != (cg[k + 1] & 0xf)) cg[l++] = cg[k];
-			else cg[k + 1] += cg[k] >> 4 << 4;
-		n = l;
-	}
-	if ((cg[0] & 0xf) == 1 || (cg[0] & 0xf) == 2) { // get rid of leading I or D
-		const int32_t l = (int32_t)(cg[0] >> 4);
-		if ((cg[0] & 0xf) == 1) { if (r.rev) r.qe -= l; else r.qs += l; *qshift = l; }
-		else r.rs += l, *tshift = l;
-		--n;
-		memmove(cg.data(), cg.data() + 1, (size_t)n * 4);
-	}
-	cg.resize(n);
+	if (P.qshift) { if (r.rev) r.qe -= P.qshift; else r.qs += P.qshift; }
+	r.rs += P.tshift;
+	r.mlen = P.mlen, r.blen = P.blen, r.n_ambi += P.n_ambi, r.dp_max = P.dp_max;
 }
 
 static inline void gd_update_extra(GdReg &r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int log_gap)
 {
-	int32_t qshift, tshift, toff = 0, qoff = 0;
-	double s = 0.0, mx = 0.0;
 	if (!r.has_p) return;
-	gd_fix_cigar(r, qseq, tseq, &qshift, &tshift);
-	qseq += qshift, tseq += tshift;
-	r.blen = r.mlen = 0;
-	for (uint32_t k = 0; k < r.cigar.size(); ++k) {
-		const uint32_t op = r.cigar[k] & 0xf, len = r.cigar[k] >> 4;
-		if (op == 0) {
-			int n_ambi = 0, n_diff = 0;
-			for (uint32_t l = 0; l < len; ++l) {
-				const int cq = qseq[qoff + l], ct = tseq[toff + l];
-				if (ct > 3 || cq > 3) ++n_ambi;
-				else if (ct != cq) ++n_diff;
-				// the reference indexes mat[ct*5+cq] with cq possibly 7 (N of a reverse-complemented read): that lands in the
-				// next matrix row, or past the 25 entries for ct = 4 (undefined there; taken as 0 here)
-				s += (ct * 5 + cq < 25) ? mat[ct * 5 + cq] : 0;
-				if (s < 0) s = 0;
-				else mx = mx > s ? mx : s;
-			}
-			r.blen += len - n_ambi, r.mlen += len - (n_ambi + n_diff), r.n_ambi += n_ambi;
-			toff += len, qoff += len;
-		} else if (op == 1 || op == 2) {
-			int n_ambi = 0;
-			for (uint32_t l = 0; l < len; ++l)
-				if ((op == 1 ? qseq[qoff + l] : tseq[toff + l]) > 3) ++n_ambi;
-			r.blen += len - n_ambi, r.n_ambi += n_ambi;
-			if (log_gap) s -= q + (double)e * gd_mg_log2(1.0f + (float)len);
-			else s -= q + e;
-			if (s < 0) s = 0;
-			if (op == 1) qoff += len; else toff += len;
-		} else if (op == 3) toff += len;
-	}
-	r.dp_max = (int32_t)(mx + .499);
+	uint32_t n = (uint32_t)r.cigar.size();
+	GdPostOut P;
+	gdp_update_extra(r.cigar.data(), &n, qseq, tseq, mat, q, e, log_gap, &P);
+	r.cigar.resize(n);
+	gd_apply_post(r, P);
 }
 
 // ---- P2: concatenate_cigars, LR/map.c:41-640 (bug-compatible: junction search adds al_start_a twice, :267,:493) ---------
@@ -554,7 +471,8 @@ struct GdDpResult { int32_t score; const uint32_t *cigar; int32_t n_cigar; };
 
 // enc_for / enc_rev: the read encoded 0-4 on the forward strand / reverse-complemented (LR/map.c:1622-1643)
 static inline void gd_lr_finish(std::vector<GdCand> &C, const std::vector<GdDpResult> &dp, const GdMapOpt &O, const GdRefView &R,
-                                uint32_t qlen_sum, const uint8_t *enc_for, const uint8_t *enc_rev, std::vector<GdReg> &out, FILE *trace = nullptr)
+                                uint32_t qlen_sum, const uint8_t *enc_for, const uint8_t *enc_rev, std::vector<GdReg> &out, FILE *trace = nullptr,
+                                const GdPostOut *post = nullptr /* P1 already done on the device: one entry per candidate, CIGARs already fixed */)
 {
 	out.clear();
 	const unsigned n = (unsigned)C.size();
@@ -571,10 +489,13 @@ static inline void gd_lr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 		r.has_p = true;
 		r.cigar.assign(dp[i].cigar, dp[i].cigar + dp[i].n_cigar);
 		r.dp_score = dp[i].score;
-		tseq.assign((size_t)c.tlen + 16, 0);
-		gd_getseq(R, c.target_id, c.target_start, c.target_end + 1, tseq.data());
-		const uint8_t *qseq = (c.v.str ? enc_rev : enc_for) + c.qseq_off;
-		gd_update_extra(r, qseq, tseq.data(), mat, (int8_t)O.q, (int8_t)O.e, !(O.flag & GD_F_SR));
+		if (post) gd_apply_post(r, post[i]);
+		else {
+			tseq.assign((size_t)c.tlen + 16, 0);
+			gd_getseq(R, c.target_id, c.target_start, c.target_end + 1, tseq.data());
+			const uint8_t *qseq = (c.v.str ? enc_rev : enc_for) + c.qseq_off;
+			gd_update_extra(r, qseq, tseq.data(), mat, (int8_t)O.q, (int8_t)O.e, !(O.flag & GD_F_SR));
+		}
 		const uint32_t clip0 = r.rev ? qlen_sum - r.qe : (uint32_t)r.qs, clip1 = r.rev ? (uint32_t)r.qs : qlen_sum - r.qe;
 		if (!(clip0 < qlen_sum && clip1 < qlen_sum)) { c.valid = 0; continue; }
 		c.r = r;
@@ -690,7 +611,7 @@ static inline void gd_sr_boxes(std::vector<GdCand> &C, const GdMapOpt &O, const 
 
 // ---- SR/map.c:931-984: records after the DP -- mm_update_extra, clip / min_dp_max filter, insertion by score, mapq ------------
 static inline void gd_sr_finish(std::vector<GdCand> &C, const std::vector<GdDpResult> &dp, const GdMapOpt &O, const GdRefView &R,
-                                uint32_t qlen_sum, const uint8_t *enc_for, const uint8_t *enc_rev, std::vector<GdReg> &out)
+                                uint32_t qlen_sum, const uint8_t *enc_for, const uint8_t *enc_rev, std::vector<GdReg> &out, const GdPostOut *post = nullptr)
 {
 	out.clear();
 	const int g = O.a, bb = O.b < 0 ? O.b : -O.b;
@@ -708,10 +629,13 @@ static inline void gd_sr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 		r.has_p = true;
 		r.cigar.assign(dp[i].cigar, dp[i].cigar + (dp[i].n_cigar > 0 ? dp[i].n_cigar : 0));
 		r.dp_score = dp[i].score;
-		tseq.assign((size_t)c.tlen + 16, 0);
-		gd_getseq(R, c.target_id, c.target_start, c.target_end + 1, tseq.data());
-		const uint8_t *qseq = (c.v.str ? enc_rev : enc_for) + c.qseq_off;
-		gd_update_extra(r, qseq, tseq.data(), mat, (int8_t)O.q, (int8_t)O.e, !(O.flag & GD_F_SR));
+		if (post) gd_apply_post(r, post[i]);
+		else {
+			tseq.assign((size_t)c.tlen + 16, 0);
+			gd_getseq(R, c.target_id, c.target_start, c.target_end + 1, tseq.data());
+			const uint8_t *qseq = (c.v.str ? enc_rev : enc_for) + c.qseq_off;
+			gd_update_extra(r, qseq, tseq.data(), mat, (int8_t)O.q, (int8_t)O.e, !(O.flag & GD_F_SR));
+		}
 		const uint32_t clip0 = r.rev ? qlen_sum - r.qe : (uint32_t)r.qs, clip1 = r.rev ? (uint32_t)r.qs : qlen_sum - r.qe;
 		if (!(clip0 < qlen_sum && clip1 < qlen_sum) || r.dp_score < O.min_dp_max) continue;
 		out.push_back(std::move(r));

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "map_stages.h"
+#include "map_post.h"
 
 struct MapDevOpt { // uniform per batch
 	int32_t k, w;
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const in
 }
 
 // one DP box: where its query / target windows come from and where they go in the packed ksw batch buffers
+#define GD_NEG_INF_SCORE_DEV (-0x40000000)
 struct MapBox {
 	int64_t read_off;   // offset of the read in the nt4 read buffer
 	int64_t q_dst, t_dst; // destination offsets in the packed query / target buffers
@@ -274,6 +276,28 @@ __global__ __launch_bounds__(64) void map_pack_cigar_kernel(int nb, const uint32
 	if (b >= nb) return;
 	const int64_t n = poff[b + 1] - poff[b];
 	for (int64_t i = threadIdx.x; i < n; i += blockDim.x) packed[poff[b] + i] = cig[coff[b] + i];
+}
+
+// P1 on the device: mm_fix_cigar + mm_update_extra of every alignment of the batch, one thread per alignment,
+// right behind the backtrack.  The CIGAR is rewritten in its slot, n_cigar updated, and the scalars the host needs for the record
+// (shifts of qs / qe / rs, mlen, blen, n_ambi, dp_max) land in post[b].  The windows are the ones the DP read (qbuf / tbuf): the
+// host then needs neither the 4-bit reference nor the reverse-complemented read for P1.
+struct MapPostOpt { int8_t mat[25]; int8_t q, e; int32_t log_gap; };
+__global__ __launch_bounds__(64) void map_post_kernel(int nb, const MapBox *__restrict__ boxes, const uint8_t *__restrict__ qbuf, const uint8_t *__restrict__ tbuf,
+                                                      const int64_t *__restrict__ coff, uint32_t *__restrict__ cig, int32_t *__restrict__ n_cigar,
+                                                      const int32_t *__restrict__ score, MapPostOpt O, GdPostOut *__restrict__ post)
+{
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nb) return;
+	GdPostOut P;
+	P.qshift = P.tshift = P.mlen = P.blen = P.dp_max = 0, P.n_ambi = 0;
+	const int32_t n0 = n_cigar[b];
+	if (score[b] != GD_NEG_INF_SCORE_DEV && n0 > 0 && (int64_t)n0 <= coff[b + 1] - coff[b]) { // (an overflowing CIGAR is reported by the host)
+		uint32_t n = (uint32_t)n0;
+		gdp_update_extra(cig + coff[b], &n, qbuf + boxes[b].q_dst, tbuf + boxes[b].t_dst, O.mat, O.q, O.e, O.log_gap, &P);
+		n_cigar[b] = (int32_t)n;
+	}
+	post[b] = P;
 }
 
 // ---- wave-parallel form of map_seed_kernel: one 64-lane wavefront per read -------------------------------------------

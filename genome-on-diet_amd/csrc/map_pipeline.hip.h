@@ -549,6 +549,9 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	mark("g:fill");
 	if ((rc = gd_host_grow(ctx, ctx->h_res, sizeof(int32_t) * 2 * (size_t)std::max(nb, 1)))) return rc;
 	int32_t *h_score = (int32_t *)ctx->h_res.p, *h_ncig = h_score + nb;
+	const bool post_dev = ctx->post_on_device != 0;
+	if (post_dev && (rc = gd_host_grow(ctx, ctx->h_post, sizeof(GdPostOut) * (size_t)std::max(nb, 1)))) return rc;
+	const GdPostOut *h_post = (const GdPostOut *)ctx->h_post.p;
 	uint32_t *h_cig = nullptr;
 	std::vector<int64_t> poff(1, 0);
 	// an async lane shares its parent's backtrace arena (two whole-batch arenas do not fit in HBM, and concurrent DP kernels of
@@ -592,6 +595,16 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			if (!ctx->own_arena) GD_HIP(hipEventRecord(ctx->parent->arena_ev, sd)); // the backtrack is done by then: the CIGARs sit in this lane's own buffer
 			if (dp_lock.owns_lock()) dp_lock.unlock();
 		}
+		if (post_dev) { // P1 on the device, behind the backtrack of this stage (reads this lane's own windows and CIGAR slots, not the arena)
+			if ((rc = gd_grow(ctx, ctx->m_post, sizeof(GdPostOut) * (size_t)nb))) { (void)hipStreamSynchronize(sd); return rc; }
+			MapPostOpt PO;
+			const int g_ = O.a, bb_ = O.b < 0 ? O.b : -O.b;
+			for (int i = 0; i < 25; ++i) PO.mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? (int8_t)g_ : (int8_t)bb_);
+			PO.q = (int8_t)O.q, PO.e = (int8_t)O.e, PO.log_gap = !(O.flag & GD_F_SR);
+			hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+			                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p);
+			GD_HIP(hipMemcpyAsync(ctx->h_post.p, ctx->m_post.p, sizeof(GdPostOut) * (size_t)nb, hipMemcpyDeviceToHost, sd));
+		}
 		GD_HIP(hipMemcpyAsync(h_score, d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipMemcpyAsync(h_ncig, d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipStreamSynchronize(sd));
@@ -631,8 +644,9 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		for (size_t j = 0; j < nc; ++j) gd_cand_unbox(cflat[(size_t)cfirst[i] + j], C[j]);
 		const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
 		const uint8_t *enc = B.enc + B.roff[i];
+		// the reverse-complemented read: for P1 on the host, else only where a reverse-strand candidate may be concatenated (P2)
 		bool need_rev = false;
-		for (auto &c : C) need_rev |= c.v.str != 0;
+		for (auto &c : C) need_rev |= c.v.str != 0 && (!post_dev || c.next >= 0);
 		if (need_rev) { rev.resize(rl); for (uint32_t j = 0; j < rl; ++j) rev[rl - 1 - j] = enc[j] ^ 3; }
 		dp.resize(nc);
 		for (size_t j = 0; j < nc; ++j) {
@@ -641,8 +655,9 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		}
 		static thread_local std::vector<GdReg> out;
 		out.clear();
-		if (is_sr) gd_sr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
-		else gd_lr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out);
+		const GdPostOut *pre = post_dev ? h_post + box_first[i] : nullptr;
+		if (is_sr) gd_sr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out, pre);
+		else gd_lr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out, nullptr, pre);
 		if (out.empty()) return;
 		bool head = false;
 		void *at = gd_reg_slab_take(call_id, gd_regs_bytes(out), head);
@@ -700,7 +715,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		gdiet_ctx *c = nullptr;
 		int rc = gdiet_hip_init(&c, ctx->device);
 		if (rc) { ctx->err = "cannot create a pipeline lane"; return rc; }
-		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves;
+		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves, c->post_on_device = ctx->post_on_device;
 		ctx->children.push_back(c);
 	}
 	const int n_slices = std::min(n, lanes * ctx->slices_per_lane);
@@ -798,7 +813,7 @@ extern "C" int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *ix, const
 		ctx->async_lane[l] = c;
 	}
 	gdiet_ctx *c = ctx->async_lane[l];
-	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves;
+	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves, c->post_on_device = ctx->post_on_device;
 	c->lane_threads = c->host_threads = ctx->host_threads; // all lanes draw from the parent's pool
 	ctx->async_busy[l] = true, ctx->async_next++;
 	t->lane = l;
