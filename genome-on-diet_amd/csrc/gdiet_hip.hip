@@ -44,6 +44,7 @@ struct gdiet_ctx {
 	hipStream_t stream_dp = nullptr;   // stream of the DP stage in an async lane (GDIET_DP_PRIORITY=1 raises its priority)
 	hipEvent_t ev2[3] = {nullptr, nullptr, nullptr}; // go, DP of the tail done, tail done
 	int dp_split = 1, wave_slots = 5120, last_split = 0;
+	int wide_ckpt = -1;                // GDIET_WIDE_CKPT: 1 / 0 force / forbid the checkpointed wide-band kernel, default by batch size
 	int wide_two_waves = -1;           // GDIET_WIDE_TWO_WAVES: 1 / 0 force the two-wavefront / two-blocks-per-lane kernel for wide bands, default by count
 	int vote_wave = 1;                 // GDIET_VOTE_WAVE=0: the sequential vote kernel for long reads too
 	int index_on_device = 1;           // GDIET_INDEX_BUILD=host: gdiet_hip_index_build sketches and sorts on host threads instead
@@ -194,6 +195,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (bw) ctx->bt_wave = atoi(bw) != 0;
 		const char *tw = getenv("GDIET_WIDE_TWO_WAVES");
 		if (tw) ctx->wide_two_waves = atoi(tw) != 0;
+		const char *wc = getenv("GDIET_WIDE_CKPT");
+		if (wc) ctx->wide_ckpt = atoi(wc) != 0;
 		const char *vw = getenv("GDIET_VOTE_WAVE");
 		if (vw) ctx->vote_wave = atoi(vw) != 0;
 		const char *ib = getenv("GDIET_INDEX_BUILD");
@@ -440,10 +443,23 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 			cells_sum += cells;
 			alg_sum += cells + (uint64_t)(T.qlen + T.tlen) + (uint64_t)T.qlen + (uint64_t)(T.tlen + 1) / 2;
 		}
-		T.bt_off = (int64_t)bt;
-		bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
 		ids[T.kind].push_back(i);
 		ctx->last_mask |= T.kind == GD_KIND_GENERIC ? 2 : T.kind == GD_KIND_WAVE16 ? 4 : T.kind == GD_KIND_WAVE128 ? 8 : 1;
+	}
+	// Wide-band alignments (ONT): 134 MB of backtrace per 50 kbp alignment.  When the batch holds enough of them to fill the GPU, or their
+	// backtraces would not fit beside the rest, they run on the checkpointed kernel (snapshots + one chunk of rows: ~5 MB each,
+	// ksw_extd2_wave128c_kernel), which needs the fused backtrack.  GDIET_WIDE_CKPT=0 / 1 forces the choice.
+	bool wide_ck = false;
+	if (!ids[GD_KIND_WAVE128].empty() && ctx->fuse_bt && !(ctx->single_affine && K.q == K.q2 && K.e == K.e2)) {
+		size_t full = 0;
+		for (int32_t id : ids[GD_KIND_WAVE128]) full += (size_t)(h_tasks[id].qlen + h_tasks[id].tlen - 1) * (size_t)h_tasks[id].row_bytes;
+		wide_ck = ctx->wide_ckpt == 1 || (ctx->wide_ckpt < 0 && ((int)ids[GD_KIND_WAVE128].size() >= ctx->wave_slots / 5 || full > ((size_t)100 << 30)));
+	}
+	for (int i = 0; i < n; ++i) {
+		KswTask &T = h_tasks[i];
+		T.bt_off = (int64_t)bt;
+		if (wide_ck && T.kind == GD_KIND_WAVE128) bt += gd_align256(gd_ck_bytes(T.qlen, T.tlen, T.row_bytes) + 64);
+		else bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
 	}
 	// longest alignments first inside each class: the tail of the grid is then made of short jobs (a class whose members all have
 	// one geometry -- a short-read batch -- is in order already)
@@ -595,8 +611,10 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		// few wide-band alignments (the arena bounds how many 50 kbp ONT alignments fit): two wavefronts share one, halving the
 		// serial chain; plenty of them: one wavefront each, two blocks per lane, no barrier
 		const int n128 = (int)ids[GD_KIND_WAVE128].size();
-		const bool two = ctx->wide_two_waves == 1 || (ctx->wide_two_waves < 0 && n128 < ctx->wave_slots / 2);
-		if (two)
+		const bool two = !wide_ck && (ctx->wide_two_waves == 1 || (ctx->wide_two_waves < 0 && n128 < ctx->wave_slots / 2));
+		if (wide_ck)
+			gd_launch_wave128(d_tasks, d_ids + id_off[GD_KIND_WAVE128], n128, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, d_n_cigar, d_cigar, true);
+		else if (two)
 			gd_launch_wave2x64(d_tasks, d_ids + id_off[GD_KIND_WAVE128], n128, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream,
 			                   fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
 		else

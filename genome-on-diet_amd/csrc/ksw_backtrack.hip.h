@@ -220,6 +220,74 @@ __device__ __forceinline__ void gd_bt_wave_walk(const KswTask &T, int tid, const
 	}
 }
 
+// The same walk in resumable form, for a backtrace that exists one chunk of anti-diagonals at a time (ksw_extd2_wave128c_kernel):
+// gd_walk_rows consumes cells while their anti-diagonal is >= r0 (rows of `chunk`, row r at (r - r0) * row_bytes, the layout of
+// the two-blocks-per-lane kernel) and returns with its state, to be called again on the chunk below.
+struct GdWalk { int i, j, state, have, nc; uint32_t last; };
+__device__ __forceinline__ void gd_walk_init(GdWalk &W, int qlen, int tlen) { W.i = tlen - 1, W.j = qlen - 1, W.state = 0, W.have = 0, W.nc = 0, W.last = 0; }
+__device__ __forceinline__ void gd_walk_push(GdWalk &W, uint32_t *cg, int cap, int lane, uint32_t op, uint32_t len)
+{
+	if (W.have && (W.last & 0xf) == op) W.last += len << 4;
+	else {
+		if (W.have) { if (W.nc < cap && lane == 0) cg[W.nc] = W.last; ++W.nc; }
+		W.last = len << 4 | op, W.have = 1;
+	}
+}
+__device__ __forceinline__ void gd_walk_rows(GdWalk &W, const KswTask &T, const uint8_t *__restrict__ chunk, int r0, int qlen, int tlen, int w,
+                                             uint32_t *__restrict__ cigar, int lane)
+{
+	uint32_t *cg = cigar + T.cig_off;
+	const int cap = __builtin_amdgcn_readfirstlane(T.cig_cap);
+	const size_t row_bytes = (size_t)__builtin_amdgcn_readfirstlane(T.row_bytes);
+	while (W.i >= 0 && W.j >= 0 && W.i + W.j >= r0) {
+		const int i0 = W.i, j0 = W.j;
+		const int ik = i0 - lane, jk = j0 - lane;
+		int fs = -1;
+		uint32_t pf = 0;
+		if (ik >= 0 && jk >= 0 && ik + jk >= r0) {
+			const int r = ik + jk;
+			int st0, en0;
+			gd_band(r, qlen, tlen, w, st0, en0);
+			const int off = st0 & ~15, off_end = en0 | 15;
+			if (ik < off) fs = 2;
+			if (ik > off_end) fs = 1;
+			if (fs < 0) {
+				const int c = ik & 15, g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
+				pf = chunk[(size_t)(r - r0) * row_bytes + (size_t)(((ik >> 4) - (off >> 4)) << 4) + (g << 2) + h];
+			}
+		}
+		for (int k = 0; k < 64; ++k) {
+			if (W.i != i0 - k || W.j != j0 - k || W.i < 0 || W.j < 0 || W.i + W.j < r0) break; // left the fetched diagonal, the chunk, or finished
+			const int force_state = __builtin_amdgcn_readlane(fs, k);
+			uint32_t tmp = (uint32_t)__builtin_amdgcn_readlane((int)pf, k);
+			if (force_state < 0) tmp = gd_bt_decode(tmp);
+			if (W.state == 0) W.state = tmp & 7;
+			else if (!(tmp >> (W.state + 2) & 1)) W.state = 0;
+			if (W.state == 0) W.state = tmp & 7;
+			if (force_state >= 0) W.state = force_state;
+			if (W.state == 0) { gd_walk_push(W, cg, cap, lane, 0, 1); --W.i, --W.j; }
+			else if (W.state == 1 || W.state == 3) { gd_walk_push(W, cg, cap, lane, 2, 1); --W.i; }
+			else { gd_walk_push(W, cg, cap, lane, 1, 1); --W.j; }
+		}
+	}
+}
+__device__ __forceinline__ void gd_walk_finish(GdWalk &W, const KswTask &T, int tid, int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar, int lane)
+{
+	uint32_t *cg = cigar + T.cig_off;
+	const int cap = __builtin_amdgcn_readfirstlane(T.cig_cap);
+	if (W.i >= 0) gd_walk_push(W, cg, cap, lane, 2, (uint32_t)(W.i + 1));
+	if (W.j >= 0) gd_walk_push(W, cg, cap, lane, 1, (uint32_t)(W.j + 1));
+	if (W.have) { if (W.nc < cap && lane == 0) cg[W.nc] = W.last; ++W.nc; }
+	if (lane == 0) n_cigar[tid] = W.nc;
+	if (W.nc <= cap) {
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		for (int k = lane; k < W.nc >> 1; k += 64) {
+			const uint32_t t0 = cg[k];
+			cg[k] = cg[W.nc - 1 - k], cg[W.nc - 1 - k] = t0;
+		}
+	}
+}
+
 __global__ __launch_bounds__(256) void ksw_backtrack_wave_kernel(const KswTask *__restrict__ tasks, int n,
                                                                  const uint8_t *__restrict__ bt,
                                                                  const int32_t *__restrict__ status,

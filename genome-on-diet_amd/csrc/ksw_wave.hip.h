@@ -38,6 +38,7 @@ __device__ __forceinline__ u32 gdw_seam_byte(const uint8_t *query, int qlen, int
 // v_readfirstlane_b32: five vector instructions per anti-diagonal)
 __device__ __forceinline__ void gdw_band_uniform(int r, int qlen, int tlen, int w, int &st0, int &en0)
 {
+	r = __builtin_amdgcn_readfirstlane(r); // (wave-uniform by contract; the compiler cannot always prove it)
 	int a = r - qlen + 1, b = (r - w + 1) >> 1, c = (r + w) >> 1, t1 = tlen - 1, st, en;
 	asm("s_max_i32 %0, %1, %2\n\ts_max_i32 %0, %0, 0" : "=&s"(st) : "s"(a), "s"(b) : "scc");
 	asm("s_min_i32 %0, %1, %2\n\ts_min_i32 %0, %0, %3" : "=&s"(en) : "s"(t1), "s"(r), "s"(c) : "scc");
@@ -223,6 +224,91 @@ template <int G> static inline void gd_launch_wave_groups(const KswTask *tasks, 
 // neighbour of sub-block 1 is sub-block 0 of the same lane (plain register copies taken before the row is updated), the
 // neighbour of sub-block 0 is sub-block 1 of the previous lane (DPP wave_ror:1).  Everything else is the 64-lane kernel
 // applied to each sub-block.
+struct Wave128State {
+	WaveLane L0, L1;
+	bool any_tn;
+	int prev_st_, prev_st0, prev_up, prev_en0, have_f, Rf;
+};
+
+__device__ __forceinline__ void gdw128_init(Wave128State &S, const WaveK &K, int lane, const uint8_t *query, int qlen, const uint8_t *target, int tlen)
+{
+	gdw_load_block(S.L0, K, 2 * lane, 0, query, qlen, target, tlen);
+	gdw_load_block(S.L1, K, 2 * lane + 1, 0, query, qlen, target, tlen);
+	S.any_tn = __builtin_amdgcn_ballot_w64((S.L0.tn | S.L1.tn) != 0) != 0;
+	S.prev_st_ = 0, S.prev_st0 = -1, S.prev_up = -1, S.prev_en0 = -1, S.have_f = 0, S.Rf = 0;
+}
+
+// one anti-diagonal.  pr: where this row's backtrace goes (the reference's own n_col_ blocks, block b at (b - st_) * 16,
+// SR/ksw2.h:142: 1.5x less than a 128-block ring); STORE = false: the row is computed for its state and score only (first pass of
+// the checkpointed form: the flag / direction bytes are dead code then)
+template <bool STORE>
+__device__ __forceinline__ void gdw128_row(Wave128State &S, const WaveK &K, int r, int qlen, int tlen, int w, const uint8_t *query, const uint8_t *target,
+                                           uint8_t *pr, int mlast, int sl)
+{
+	constexpr int NBLK = 128;
+	WaveLane &L0 = S.L0, &L1 = S.L1;
+	WaveRow W;
+	W.r = r;
+	gdw_band_uniform(r, qlen, tlen, w, W.st0, W.en0);
+	W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+	W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+	const int advanced = W.st_ > S.prev_st_;
+	W.use_array = advanced;
+	W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
+	W.set_tr = (W.en0 | 15) >= r;
+	W.ukey = gdw_edge_key(K, r);
+	// (1) row r-1 values of the block below each sub-block, taken before anything is touched
+	const u32 pX0 = gdw_ror1<64>(L1.X[7]), pV0 = gdw_ror1<64>(L1.V[7]), pX20 = gdw_ror1<64>(L1.X2[7]), pQ0 = gdw_ror1<64>(L1.Qc[3]);
+	const u32 pX1 = L0.X[7], pV1 = L0.V[7], pX21 = L0.X2[7], pQ1 = L0.Qc[3];
+	// (2) query window advance; a sub-block that fell below the window takes over block +128
+	if (r > 0) {
+		const u32 seam = gdw_seam_byte(query, qlen, r - (S.prev_st_ << 4));
+		gdw_shift_query(L0, pQ0, L0.blk == S.prev_st_, seam);
+		gdw_shift_query(L1, pQ1, L1.blk == S.prev_st_, seam);
+	}
+	if (advanced) {
+		if (L0.blk < W.st_) gdw_load_block(L0, K, L0.blk + NBLK, r, query, qlen, target, tlen);
+		if (L1.blk < W.st_) gdw_load_block(L1, K, L1.blk + NBLK, r, query, qlen, target, tlen);
+		S.any_tn = __builtin_amdgcn_ballot_w64((L0.tn | L1.tn) != 0) != 0;
+	}
+	// (3) scalar fix-ups and the score row
+	if (W.set_tr) gdw_reset_tr(L0, K, W), gdw_reset_tr(L1, K, W);
+	if (W.st0 != S.prev_st0 || W.up != S.prev_up || advanced) gdw_make_sel(L0, W.st0, W.up), gdw_make_sel(L1, W.st0, W.up);
+	gdw_update_scores(L0, K, S.any_tn);
+	gdw_update_scores(L1, K, S.any_tn);
+	// (4) DP cells of the sub-blocks inside the reference's 16-aligned window
+	if (L0.blk <= W.en_) {
+		u32 out[4];
+		gdw_compute(L0, K, W, pX0, pV0, pX20, out);
+		if (STORE) *reinterpret_cast<uint4 *>(pr + ((L0.blk - W.st_) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+	}
+	if (L1.blk <= W.en_) {
+		u32 out[4];
+		gdw_compute(L1, K, W, pX1, pV1, pX21, out);
+		if (STORE) *reinterpret_cast<uint4 *>(pr + ((L1.blk - W.st_) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+	}
+	// (5) score trackers
+	if (r == 0) L0.R = gdw_lo(L0.V[0]) - K.B1 - K.qe8, L1.R = gdw_lo(L1.V[0]) - K.B1 - K.qe8;
+	else L0.R += gdw_lo(L0.V[0]) - K.B1, L1.R += gdw_lo(L1.V[0]) - K.B1;
+	if (r > 0 && W.en0 != S.prev_en0 && (W.en0 & 15) == 0) {
+		const int h0 = (int)gdw_ror1<64>((u32)gdw_track_handoff(L1)), h1 = gdw_track_handoff(L0);
+		if (L0.blk == W.en_) L0.R = h0 + gdw_lo(L0.U[0]);
+		if (L1.blk == W.en_) L1.R = h1 + gdw_lo(L1.U[0]);
+	}
+	if (W.en0 == tlen - 1) {
+		if (L0.blk == mlast) {
+			if (!S.have_f) S.Rf = gdw_track_to_slot(L0, sl);
+			else S.Rf += gdw_cell(L0.V, sl) - K.B1;
+		}
+		if (L1.blk == mlast) {
+			if (!S.have_f) S.Rf = gdw_track_to_slot(L1, sl);
+			else S.Rf += gdw_cell(L1.V, sl) - K.B1;
+		}
+		S.have_f = 1;
+	}
+	S.prev_st_ = W.st_, S.prev_st0 = W.st0, S.prev_up = W.up, S.prev_en0 = W.en0;
+}
+
 __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *__restrict__ tasks,
                                                                 const int32_t *__restrict__ task_ids, int n_tasks,
                                                                 const uint8_t *__restrict__ qseq,
@@ -231,7 +317,6 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *_
                                                                 int32_t *__restrict__ score_out, WaveK K,
                                                                 int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
 {
-	constexpr int NBLK = 128;
 	const int lane = threadIdx.x & 63;
 	const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
 	if (slot >= n_tasks) return;
@@ -246,79 +331,12 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *_
 	const size_t row_bytes = (size_t)__builtin_amdgcn_readfirstlane(Tp->row_bytes);
 	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
 
-	WaveLane L0, L1;
-	gdw_load_block(L0, K, 2 * lane, 0, query, qlen, target, tlen);
-	gdw_load_block(L1, K, 2 * lane + 1, 0, query, qlen, target, tlen);
-	bool any_tn = __builtin_amdgcn_ballot_w64((L0.tn | L1.tn) != 0) != 0;
-	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
-	for (int r = 0; r <= rend; ++r) {
-		WaveRow W;
-		W.r = r;
-		gdw_band_uniform(r, qlen, tlen, w, W.st0, W.en0);
-		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
-		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
-		const int advanced = W.st_ > prev_st_;
-		W.use_array = advanced;
-		W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
-		W.set_tr = (W.en0 | 15) >= r;
-		W.ukey = gdw_edge_key(K, r);
-		// (1) row r-1 values of the block below each sub-block, taken before anything is touched
-		const u32 pX0 = gdw_ror1<64>(L1.X[7]), pV0 = gdw_ror1<64>(L1.V[7]), pX20 = gdw_ror1<64>(L1.X2[7]), pQ0 = gdw_ror1<64>(L1.Qc[3]);
-		const u32 pX1 = L0.X[7], pV1 = L0.V[7], pX21 = L0.X2[7], pQ1 = L0.Qc[3];
-		// (2) query window advance; a sub-block that fell below the window takes over block +128
-		if (r > 0) {
-			const u32 seam = gdw_seam_byte(query, qlen, r - (prev_st_ << 4));
-			gdw_shift_query(L0, pQ0, L0.blk == prev_st_, seam);
-			gdw_shift_query(L1, pQ1, L1.blk == prev_st_, seam);
-		}
-		if (advanced) {
-			if (L0.blk < W.st_) gdw_load_block(L0, K, L0.blk + NBLK, r, query, qlen, target, tlen);
-			if (L1.blk < W.st_) gdw_load_block(L1, K, L1.blk + NBLK, r, query, qlen, target, tlen);
-			any_tn = __builtin_amdgcn_ballot_w64((L0.tn | L1.tn) != 0) != 0;
-		}
-		// (3) scalar fix-ups and the score row
-		if (W.set_tr) gdw_reset_tr(L0, K, W), gdw_reset_tr(L1, K, W);
-		if (W.st0 != prev_st0 || W.up != prev_up || advanced) gdw_make_sel(L0, W.st0, W.up), gdw_make_sel(L1, W.st0, W.up);
-		gdw_update_scores(L0, K, any_tn);
-		gdw_update_scores(L1, K, any_tn);
-		// (4) DP cells of the sub-blocks inside the reference's 16-aligned window
-		// backtrace row = the reference's own n_col_ blocks, block b at (b - st_) * 16 (SR/ksw2.h:142): 1.5x less arena than a
-		// 128-block ring, which is what bounds the number of 50 kbp alignments in flight
-		uint8_t *pr = p + (size_t)r * row_bytes;
-		if (L0.blk <= W.en_) {
-			u32 out[4];
-			gdw_compute(L0, K, W, pX0, pV0, pX20, out);
-			*reinterpret_cast<uint4 *>(pr + ((L0.blk - W.st_) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
-		}
-		if (L1.blk <= W.en_) {
-			u32 out[4];
-			gdw_compute(L1, K, W, pX1, pV1, pX21, out);
-			*reinterpret_cast<uint4 *>(pr + ((L1.blk - W.st_) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
-		}
-		// (5) score trackers
-		if (r == 0) L0.R = gdw_lo(L0.V[0]) - K.B1 - K.qe8, L1.R = gdw_lo(L1.V[0]) - K.B1 - K.qe8;
-		else L0.R += gdw_lo(L0.V[0]) - K.B1, L1.R += gdw_lo(L1.V[0]) - K.B1;
-		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 15) == 0) {
-			const int h0 = (int)gdw_ror1<64>((u32)gdw_track_handoff(L1)), h1 = gdw_track_handoff(L0);
-			if (L0.blk == W.en_) L0.R = h0 + gdw_lo(L0.U[0]);
-			if (L1.blk == W.en_) L1.R = h1 + gdw_lo(L1.U[0]);
-		}
-		if (W.en0 == tlen - 1) {
-			if (L0.blk == mlast) {
-				if (!have_f) Rf = gdw_track_to_slot(L0, sl);
-				else Rf += gdw_cell(L0.V, sl) - K.B1;
-			}
-			if (L1.blk == mlast) {
-				if (!have_f) Rf = gdw_track_to_slot(L1, sl);
-				else Rf += gdw_cell(L1.V, sl) - K.B1;
-			}
-			have_f = 1;
-		}
-		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
-	}
+	Wave128State S;
+	gdw128_init(S, K, lane, query, qlen, target, tlen);
+	for (int r = 0; r <= rend; ++r) gdw128_row<true>(S, K, r, qlen, tlen, w, query, target, p + (size_t)r * row_bytes, mlast, sl);
 	const bool fuse = cigar != nullptr; // walk the alignment back right away (see ksw_extd2_wave_kernel)
-	if (L0.blk == mlast || L1.blk == mlast) {
-		score_out[tid] = Rf >> 3;
+	if (S.L0.blk == mlast || S.L1.blk == mlast) {
+		score_out[tid] = S.Rf >> 3;
 		status[tid] = fuse ? GD_ST_TRACED : GD_ST_DONE;
 	}
 	if (fuse) {
@@ -327,13 +345,110 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *_
 	}
 }
 
+// ---- the same with a CHECKPOINTED backtrace ------------------------------------------------------------------------------------
+// A 50 kbp ONT alignment writes 134 MB of backtrace, so only ~1 500 fit the HBM at once -- fewer than the GPU has wavefront
+// slots, and the rate is bound by how many are in flight.  Here the first pass stores no backtrace at all, only a snapshot of the
+// lanes' registers every GD_CK_ROWS anti-diagonals (35 KB each); the second pass walks the alignment back chunk by chunk from the
+// end: restore the snapshot of the chunk, recompute its rows into a GD_CK_ROWS-row buffer (1.4 MB), let the walk consume them, go
+// on with the chunk below.  ~1.85x the arithmetic (the first pass drops the flag / direction bytes), 4.9 MB instead of 134 MB per
+// alignment: thousands in flight.  Rows, scores and CIGARs are those of the kernel above (same row function, same walk).
+#define GD_CK_ROWS 1024
+#define GD_CK_REGS 136 // dwords per lane per snapshot: 2 x (48 state + 16 Sb/Tb/Qc/SEL + tn, blk, R) + Rf + pad
+static inline __host__ __device__ size_t gd_ck_bytes(int qlen, int tlen, int row_bytes)
+{
+	const size_t rows = (size_t)qlen + tlen - 1, n_ck = (rows + GD_CK_ROWS - 1) / GD_CK_ROWS;
+	return n_ck * (size_t)GD_CK_REGS * 64 * 4 + (size_t)GD_CK_ROWS * (size_t)row_bytes;
+}
+
+__device__ __forceinline__ void gdw_lane_save(const WaveLane &L, u32 *d) // d: this lane's column of the snapshot, stride 64 dwords
+{
+#pragma unroll
+	for (int k = 0; k < 8; ++k) d[(k) * 64] = L.U[k], d[(8 + k) * 64] = L.V[k], d[(16 + k) * 64] = L.X[k], d[(24 + k) * 64] = L.Y[k], d[(32 + k) * 64] = L.X2[k], d[(40 + k) * 64] = L.Y2[k];
+#pragma unroll
+	for (int g = 0; g < 4; ++g) d[(48 + g) * 64] = L.Sb[g], d[(52 + g) * 64] = L.Tb[g], d[(56 + g) * 64] = L.Qc[g], d[(60 + g) * 64] = L.SEL[g];
+	d[64 * 64] = L.tn, d[65 * 64] = (u32)L.blk, d[66 * 64] = (u32)L.R;
+}
+__device__ __forceinline__ void gdw_lane_load(WaveLane &L, const u32 *d)
+{
+#pragma unroll
+	for (int k = 0; k < 8; ++k) L.U[k] = d[(k) * 64], L.V[k] = d[(8 + k) * 64], L.X[k] = d[(16 + k) * 64], L.Y[k] = d[(24 + k) * 64], L.X2[k] = d[(32 + k) * 64], L.Y2[k] = d[(40 + k) * 64];
+#pragma unroll
+	for (int g = 0; g < 4; ++g) L.Sb[g] = d[(48 + g) * 64], L.Tb[g] = d[(52 + g) * 64], L.Qc[g] = d[(56 + g) * 64], L.SEL[g] = d[(60 + g) * 64];
+	L.tn = d[64 * 64], L.blk = (int32_t)d[65 * 64], L.R = (int32_t)d[66 * 64];
+}
+
+__global__ __launch_bounds__(128) void ksw_extd2_wave128c_kernel(const KswTask *__restrict__ tasks,
+                                                                 const int32_t *__restrict__ task_ids, int n_tasks,
+                                                                 const uint8_t *__restrict__ qseq,
+                                                                 const uint8_t *__restrict__ tseq,
+                                                                 uint8_t *__restrict__ bt, int32_t *__restrict__ status,
+                                                                 int32_t *__restrict__ score_out, WaveK K,
+                                                                 int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
+{
+	const int lane = threadIdx.x & 63;
+	const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+	if (slot >= n_tasks) return;
+	const int tid = __builtin_amdgcn_readfirstlane(task_ids[slot]);
+	if (__builtin_amdgcn_readfirstlane(status[tid]) != GD_ST_PENDING) return;
+	const KswTask *Tp = tasks + tid;
+	const int qlen = __builtin_amdgcn_readfirstlane(Tp->qlen), tlen = __builtin_amdgcn_readfirstlane(Tp->tlen);
+	int w = __builtin_amdgcn_readfirstlane(Tp->w);
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const uint8_t *query = qseq + Tp->qoff, *target = tseq + Tp->toff;
+	const size_t row_bytes = (size_t)__builtin_amdgcn_readfirstlane(Tp->row_bytes);
+	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+	const int n_ck = (rend + GD_CK_ROWS) / GD_CK_ROWS; // chunks of GD_CK_ROWS anti-diagonals
+	u32 *ck = reinterpret_cast<u32 *>(bt + Tp->bt_off);                       // [n_ck][GD_CK_REGS][64]
+	uint8_t *chunk = bt + Tp->bt_off + (size_t)n_ck * GD_CK_REGS * 64 * 4;    // [GD_CK_ROWS][row_bytes]
+
+	// ---- pass 1: state and score, a snapshot at the start of every chunk ----
+	Wave128State S;
+	gdw128_init(S, K, lane, query, qlen, target, tlen);
+	for (int r = 0; r <= rend; ++r) {
+		if ((r & (GD_CK_ROWS - 1)) == 0) {
+			u32 *d = ck + (size_t)(r / GD_CK_ROWS) * GD_CK_REGS * 64 + lane;
+			gdw_lane_save(S.L0, d), gdw_lane_save(S.L1, d + 67 * 64);
+			d[134 * 64] = (u32)S.Rf;
+		}
+		gdw128_row<false>(S, K, r, qlen, tlen, w, query, target, nullptr, mlast, sl);
+	}
+	if (S.L0.blk == mlast || S.L1.blk == mlast) {
+		score_out[tid] = S.Rf >> 3;
+		status[tid] = GD_ST_TRACED;
+	}
+	// ---- pass 2: from the last chunk down, recompute a chunk's rows and let the walk consume them ----
+	GdWalk Wk;
+	gd_walk_init(Wk, qlen, tlen);
+	for (int kk = n_ck - 1; kk >= 0 && Wk.i >= 0 && Wk.j >= 0; --kk) {
+		const int k = __builtin_amdgcn_readfirstlane(kk);
+		const int r0 = k * GD_CK_ROWS, r1 = r0 + GD_CK_ROWS - 1 < rend ? r0 + GD_CK_ROWS - 1 : rend;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // the snapshot stores of pass 1 / the previous walk's reads of `chunk`
+		const u32 *d = ck + (size_t)k * GD_CK_REGS * 64 + lane;
+		gdw_lane_load(S.L0, d), gdw_lane_load(S.L1, d + 67 * 64);
+		S.Rf = (int)d[134 * 64];
+		S.any_tn = __builtin_amdgcn_ballot_w64((S.L0.tn | S.L1.tn) != 0) != 0;
+		if (r0 == 0) S.prev_st_ = 0, S.prev_st0 = -1, S.prev_up = -1, S.prev_en0 = -1, S.have_f = 0;
+		else { // the loop-carried band quantities of anti-diagonal r0 - 1
+			int st0, en0;
+			gdw_band_uniform(r0 - 1, qlen, tlen, w, st0, en0);
+			S.prev_st_ = st0 >> 4, S.prev_st0 = st0, S.prev_en0 = en0, S.prev_up = st0 + (((en0 - st0 + 16) >> 4) << 4);
+			S.have_f = en0 == tlen - 1; // en0 never decreases: the corner column was reached before r0 iff it is reached at r0 - 1
+		}
+		for (int r = r0; r <= r1; ++r) gdw128_row<true>(S, K, r, qlen, tlen, w, query, target, chunk + (size_t)(r - r0) * row_bytes, mlast, sl);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // this wavefront's own stores: complete, and not served from a stale L1 line
+		gd_walk_rows(Wk, *Tp, chunk, r0, qlen, tlen, w, cigar, lane);
+	}
+	gd_walk_finish(Wk, *Tp, tid, n_cigar, cigar, lane);
+}
+
 static inline void gd_launch_wave128(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
                                      uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int32_t *n_cigar = nullptr,
-                                     uint32_t *cigar = nullptr)
+                                     uint32_t *cigar = nullptr, bool checkpointed = false /* needs n_cigar / cigar: it walks its own alignments back */)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
-	hipLaunchKernelGGL(ksw_extd2_wave128_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	if (checkpointed) hipLaunchKernelGGL(ksw_extd2_wave128c_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else hipLaunchKernelGGL(ksw_extd2_wave128_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 }
 
 // ---- wide bands, few alignments: TWO wavefronts per alignment ----------------------------------------------------------------

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void map_vote_kernel(int n_reads, const int64_t
 // The occurrences of 64 seeds are expanded side by side (ballot + prefix count give every hit its slot on its strand), each
 // strand's hits are sorted by target with a wavefront bitonic sort in LDS, and the whole wavefront runs the (wave-uniform) vote
 // scans in lockstep on a 64-hits-per-round-trip view of the sorted arrays.
-// Reads with more than MAP_VOTE_CAP hits on a strand take the sequential path of map_vote_kernel (same code, one lane).
+// A strand with more than MAP_VOTE_CAP hits is sorted in LDS-sized runs that are then merged in global memory by the whole wavefront.
 #define MAP_VOTE_CAP 4096
 
 // Front-to-back view of a sorted hit array for the vote scans, executed by ALL lanes of the wavefront in lockstep: the lanes
@@ -200,31 +200,59 @@ __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const in
 		}
 	}
 	__syncthreads();
-	if (nf > MAP_VOTE_CAP || nr > MAP_VOTE_CAP) { // too many hits for the LDS buffers: the sequential path on the global arrays
-		if (lane == 0) {
-			o.pad = 0;
-			GdLoc *sf = gd_sort_locs(a_for, tmp, nf);
-			if (sf != a_for) for (unsigned i = 0; i < nf; ++i) a_for[i] = sf[i];
-			GdLoc *sr = gd_sort_locs(a_rev, tmp, nr);
-			if (O.is_sr) o.n_cand = gd_sr_candidates(a_for, nf, sr, nr, (uint32_t)len, so.tel, so.n_mv, O.sr, o.cand);
-			else o.n_cand = gd_lr_candidates(a_for, nf, sr, nr, (uint32_t)len, (int32_t)so.tel, O.vote, o.cand);
-		}
-		return;
-	}
-	// S7: one strand at a time through LDS: padded with +inf to a power of two, bitonic sort by target, back to its global array
+	// S7: one strand at a time through LDS: padded with +inf to a power of two, bitonic sort by target, back to its global array.
+	// A strand with more hits than the LDS buffer holds (long ONT reads: ~9 seeds per 100 bases) is sorted in runs of MAP_VOTE_CAP
+	// and the runs are merged pairwise in global memory, every lane merging one slice of the output (merge path); the sequential
+	// sort by one lane this replaces cost tens of milliseconds for such a read.
 	GdLoc inf;
 	inf.target = UINT64_MAX, inf.query = 0, inf.pad = 0;
 	for (int strand = 0; strand < 2; ++strand) {
 		GdLoc *g = strand ? a_rev : a_for;
 		const unsigned cnt = strand ? nr : nf;
 		if (cnt < 2) continue;
-		unsigned P2 = 64;
-		while (P2 < cnt) P2 <<= 1;
-		for (unsigned i = lane; i < P2; i += 64) s_buf[i] = i < cnt ? g[i] : inf;
-		__syncthreads();
-		map_bitonic_locs(s_buf, P2, lane);
-		for (unsigned i = lane; i < cnt; i += 64) g[i] = s_buf[i];
-		__syncthreads();
+		for (unsigned c0 = 0; c0 < cnt; c0 += MAP_VOTE_CAP) {
+			const unsigned m_ = cnt - c0 < MAP_VOTE_CAP ? cnt - c0 : MAP_VOTE_CAP;
+			unsigned P2 = 64;
+			while (P2 < m_) P2 <<= 1;
+			for (unsigned i = lane; i < P2; i += 64) s_buf[i] = i < m_ ? g[c0 + i] : inf;
+			__syncthreads();
+			map_bitonic_locs(s_buf, P2, lane);
+			for (unsigned i = lane; i < m_; i += 64) g[c0 + i] = s_buf[i];
+			__syncthreads();
+		}
+		if (cnt > MAP_VOTE_CAP) {
+			GdLoc *src = g, *dst = tmp; // tmp holds n_a entries: room for either strand
+			for (unsigned width = MAP_VOTE_CAP; width < cnt; width <<= 1) {
+				for (unsigned s0 = 0; s0 < cnt; s0 += 2 * width) {
+					const unsigned a_n = cnt - s0 < width ? cnt - s0 : width, b_n = cnt - s0 - a_n < width ? cnt - s0 - a_n : width;
+					const GdLoc *A = src + s0, *B = A + a_n;
+					GdLoc *out_ = dst + s0;
+					const unsigned tot = a_n + b_n, per = (tot + 63) / 64;
+					const unsigned lo = lane * per < tot ? lane * per : tot, hi = lo + per < tot ? lo + per : tot;
+					// how many of the first `lo` merged elements come from A (ties: A first)
+					unsigned x0 = lo > b_n ? lo - b_n : 0, x1 = lo < a_n ? lo : a_n;
+					while (x0 < x1) {
+						const unsigned mid = (x0 + x1) >> 1;
+						if (A[mid].target <= B[lo - mid - 1].target) x0 = mid + 1;
+						else x1 = mid;
+					}
+					unsigned i = x0, j = lo - x0;
+					for (unsigned k = lo; k < hi; ++k) {
+						const bool take_a = j >= b_n || (i < a_n && A[i].target <= B[j].target);
+						out_[k] = take_a ? A[i++] : B[j++];
+					}
+				}
+				__threadfence_block();
+				__syncthreads();
+				GdLoc *t_ = src;
+				src = dst, dst = t_;
+			}
+			if (src != g) {
+				for (unsigned i = lane; i < cnt; i += 64) g[i] = src[i];
+				__threadfence_block();
+				__syncthreads();
+			}
+		}
 	}
 	// V1 / V2 / V3 / G1a: the scans are sequential in the hits but wave-uniform, so every lane runs them in lockstep on a
 	// prefetching view of the sorted arrays (MapWaveLocs); the candidate list lives in LDS, lane by lane identical

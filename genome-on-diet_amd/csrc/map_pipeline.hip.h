@@ -715,7 +715,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 		gdiet_ctx *c = nullptr;
 		int rc = gdiet_hip_init(&c, ctx->device);
 		if (rc) { ctx->err = "cannot create a pipeline lane"; return rc; }
-		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves, c->post_on_device = ctx->post_on_device;
+		c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves, c->wide_ckpt = ctx->wide_ckpt, c->post_on_device = ctx->post_on_device;
 		ctx->children.push_back(c);
 	}
 	const int n_slices = std::min(n, lanes * ctx->slices_per_lane);
@@ -813,7 +813,7 @@ extern "C" int gdiet_hip_map_submit(gdiet_ctx *ctx, const gdiet_index *ix, const
 		ctx->async_lane[l] = c;
 	}
 	gdiet_ctx *c = ctx->async_lane[l];
-	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves, c->post_on_device = ctx->post_on_device;
+	c->kernel_mode = ctx->kernel_mode, c->seed_thread_kernel = ctx->seed_thread_kernel, c->spread = ctx->spread, c->bt_wave = ctx->bt_wave, c->dp_split = ctx->dp_split, c->fuse_bt = ctx->fuse_bt, c->vote_wave = ctx->vote_wave, c->wide_two_waves = ctx->wide_two_waves, c->wide_ckpt = ctx->wide_ckpt, c->post_on_device = ctx->post_on_device;
 	c->lane_threads = c->host_threads = ctx->host_threads; // all lanes draw from the parent's pool
 	ctx->async_busy[l] = true, ctx->async_next++;
 	t->lane = l;

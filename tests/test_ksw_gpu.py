@@ -241,18 +241,25 @@ def test_error_behaviour_of_the_abi(gpu_ctx, pkg):
     assert lib.gdiet_hip_init(C.byref(ctx2), 99) == -1  # no such device: GDIET_E_NODEVICE
 
 
-@pytest.mark.parametrize("two_waves", ["0", "1"])
+@pytest.mark.parametrize("two_waves", ["0", "1", "ckpt"])
 def test_wide_band_kernels_match_oracle(pkg, oracle, monkeypatch, two_waves):
-    """ONT bands (w = 1300: more than 64 blocks in flight) on both wide-band kernels -- two blocks per lane in one wavefront,
-    and two wavefronts per alignment exchanging their boundary through LDS -- against the oracle"""
+    """ONT bands (w = 1300: more than 64 blocks in flight) on the wide-band kernels -- two blocks per lane in one wavefront,
+    two wavefronts per alignment exchanging their boundary through LDS, and the checkpointed form of the first (no stored
+    backtrace: snapshots every 1024 anti-diagonals, chunks recomputed for the walk; alignments of 1 to 10 chunks here) -- against the oracle"""
     gdo, lib = oracle
-    monkeypatch.setenv("GDIET_WIDE_TWO_WAVES", two_waves)
+    if two_waves == "ckpt":
+        monkeypatch.setenv("GDIET_WIDE_CKPT", "1")
+    else:
+        monkeypatch.setenv("GDIET_WIDE_TWO_WAVES", two_waves)
+        monkeypatch.setenv("GDIET_WIDE_CKPT", "0")
     ctx = pkg.Context(0)
     try:
-        rng = np.random.default_rng(40 + int(two_waves))
+        rng = np.random.default_rng(40 + (2 if two_waves == "ckpt" else int(two_waves)))
         qs, ts, ws = [], [], []
         for i in range(24):
             n = int(rng.integers(1400, 5000))
+            if two_waves == "ckpt" and i % 6 == 0:
+                n = [700, 1024, 1025, 2047][i // 6 % 4]  # rend + 1 around the chunk size: one chunk, exactly two, ...
             q, t = gdo.make_pair(rng, n, 0.03, 0.02, 0.02, n_frac=0.01 if i % 5 == 0 else 0.0)
             if i % 4 == 1:
                 q = q.copy()
