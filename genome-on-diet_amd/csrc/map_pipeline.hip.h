@@ -443,7 +443,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), seed_lds, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 		GD_HIP(hipMemcpyAsync(so, ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
-		GD_HIP(hipStreamSynchronize(s));
+		GD_HIP(gd_stream_wait(ctx, s));
 		bool overflow = false;
 		for (int i = 0; i < n; ++i) overflow |= so[i].n_seeds < 0;
 		if (!overflow) break;
@@ -474,7 +474,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	if (ctx->h_vo.size() < vo_head * (size_t)n) ctx->h_vo.resize(vo_head * (size_t)n + (vo_head * (size_t)n >> 2));
 	const uint8_t *vo_raw = ctx->h_vo.data();
 	GD_HIP(hipMemcpy2DAsync(ctx->h_vo.data(), vo_head, ctx->m_voteout.p, sizeof(MapVoteOut), vo_head, (size_t)n, hipMemcpyDeviceToHost, s));
-	GD_HIP(hipStreamSynchronize(s));
+	GD_HIP(gd_stream_wait(ctx, s));
 	ctx->stage_s[1] += gd_now() - t0, t0 = gd_now();
 	mark("vote");
 	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
@@ -607,7 +607,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		}
 		GD_HIP(hipMemcpyAsync(h_score, d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
 		GD_HIP(hipMemcpyAsync(h_ncig, d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
-		GD_HIP(hipStreamSynchronize(sd));
+		GD_HIP(gd_stream_wait(ctx, sd));
 	mark("d:wait");
 		// CIGARs are short compared with their capacity (qlen+tlen): pack them on the device, then one copy
 		for (int b = 0; b < nb; ++b) if (h_ncig[b] > coff[b + 1] - coff[b]) { ctx->err = "CIGAR capacity exceeded"; return GDIET_E_CIGAR_CAP; }
@@ -622,7 +622,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			GD_HIP(hipMemcpyAsync(d_poff, poff.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, s));
 			hipLaunchKernelGGL(map_pack_cigar_kernel, dim3(nb), dim3(64), 0, s, nb, (const uint32_t *)ctx->m_cig.p, (const int64_t *)d_coff, (const int64_t *)d_poff, d_packed);
 			GD_HIP(hipMemcpyAsync(h_cig, d_packed, sizeof(uint32_t) * (size_t)poff[nb], hipMemcpyDeviceToHost, s));
-			GD_HIP(hipStreamSynchronize(s));
+			GD_HIP(gd_stream_wait(ctx, s));
 		}
 	}
 	if (dp_lock.owns_lock()) dp_lock.unlock();
