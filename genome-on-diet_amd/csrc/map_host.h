@@ -658,6 +658,52 @@ static inline void gd_fmt_int(std::string &s, long long v) // decimal, as "%lld"
 	s.append(b + n, (size_t)(24 - n));
 }
 
+// write_tags, LR/format.c:292-324 (the records of this path always carry a CIGAR; inv / split / trans_strand are never set)
+static inline void gd_write_tags(std::string &s, const GdReg &r)
+{
+	const char type = r.id == r.parent ? 'P' : 'S';
+	if (r.has_p) {
+		s += "\tNM:i:"; gd_fmt_int(s, r.blen - r.mlen + (int)r.n_ambi);
+		s += "\tms:i:"; gd_fmt_int(s, r.dp_max);
+		s += "\tAS:i:"; gd_fmt_int(s, r.dp_score);
+		s += "\tnn:i:"; gd_fmt_int(s, r.n_ambi);
+	}
+	s += "\ttp:A:"; s += type; s += "\tcm:i:"; gd_fmt_int(s, r.cnt); s += "\ts1:i:"; gd_fmt_int(s, r.score);
+	if (r.parent == r.id) { s += "\ts2:i:"; gd_fmt_int(s, r.subsc); }
+	if (r.has_p) { // mm_event_identity, LR/align.c:961-982
+		int32_t n_gap = 0, n_gapo = 0;
+		for (uint32_t cg : r.cigar) if ((cg & 0xf) == 1 || (cg & 0xf) == 2) ++n_gapo, n_gap += (int32_t)(cg >> 4);
+		const double ident = (double)r.mlen / (r.blen + (int)r.n_ambi - n_gap + n_gapo);
+		const double div = 1.0 - ident;
+		char buf[16];
+		if (div == 0.0) buf[0] = '0', buf[1] = 0;
+		else snprintf(buf, 16, "%.4f", 1.0 - ident);
+		s += "\tde:f:"; s += buf;
+	}
+}
+
+// ---- PAF record, mm_write_paf3 (LR/format.c:326-367) with rep_len = 0; reg_idx < 0: the unmapped line of --paf-no-hit ----------
+#define GD_F_OUT_CG 0x020
+#define GD_F_PAF_NO_HIT 0x8000000
+#define GD_F_QSTRAND (0x100000000LL)
+static inline void gd_write_paf(std::string &s, const GdRefView &R, const char *qname, int l_seq, const std::vector<GdReg> &regs, int reg_idx, int64_t opt_flag)
+{
+	s += qname; s += '\t'; gd_fmt_int(s, l_seq);
+	if (reg_idx < 0 || reg_idx >= (int)regs.size()) { s += "\t0\t0\t*\t*\t0\t0\t0\t0\t0\t0\trl:i:0"; return; }
+	const GdReg &r = regs[reg_idx];
+	s += '\t'; gd_fmt_int(s, r.qs); s += '\t'; gd_fmt_int(s, r.qe); s += '\t'; s += "+-"[r.rev]; s += '\t';
+	s += R.seq[r.rid].name; s += '\t'; gd_fmt_int(s, R.seq[r.rid].len);
+	if ((opt_flag & GD_F_QSTRAND) && r.rev) { s += '\t'; gd_fmt_int(s, (int64_t)R.seq[r.rid].len - r.re); s += '\t'; gd_fmt_int(s, (int64_t)R.seq[r.rid].len - r.rs); }
+	else { s += '\t'; gd_fmt_int(s, r.rs); s += '\t'; gd_fmt_int(s, r.re); }
+	s += '\t'; gd_fmt_int(s, r.mlen); s += '\t'; gd_fmt_int(s, r.blen); s += '\t'; gd_fmt_int(s, r.mapq);
+	gd_write_tags(s, r);
+	s += "\trl:i:0";
+	if (r.has_p && (opt_flag & GD_F_OUT_CG)) {
+		s += "\tcg:Z:";
+		for (uint32_t cg : r.cigar) { gd_fmt_int(s, cg >> 4); s += "MIDNSHP=XB"[cg & 0xf]; }
+	}
+}
+
 static inline void gd_write_sam(std::string &s, const GdRefView &R, const char *qname, const char *seq, const char *qual, int l_seq,
                                 const std::vector<GdReg> &regs, int reg_idx, int64_t opt_flag)
 {
@@ -712,26 +758,7 @@ static inline void gd_write_sam(std::string &s, const GdRefView &R, const char *
 			s += '\t';
 			if (qual) put_seq(qual + r->qs, r->qe - r->qs, r->rev, 0); else s += '*';
 		}
-		// tags, LR/format.c:292-324
-		const char type = r->id == r->parent ? 'P' : 'S';
-		if (r->has_p) {
-			s += "\tNM:i:"; gd_fmt_int(s, r->blen - r->mlen + (int)r->n_ambi);
-			s += "\tms:i:"; gd_fmt_int(s, r->dp_max);
-			s += "\tAS:i:"; gd_fmt_int(s, r->dp_score);
-			s += "\tnn:i:"; gd_fmt_int(s, r->n_ambi);
-		}
-		s += "\ttp:A:"; s += type; s += "\tcm:i:"; gd_fmt_int(s, r->cnt); s += "\ts1:i:"; gd_fmt_int(s, r->score);
-		if (r->parent == r->id) { s += "\ts2:i:"; gd_fmt_int(s, r->subsc); }
-		if (r->has_p) {
-			int32_t n_gap = 0, n_gapo = 0;
-			for (uint32_t cg : r->cigar) if ((cg & 0xf) == 1 || (cg & 0xf) == 2) ++n_gapo, n_gap += (int32_t)(cg >> 4);
-			const double ident = (double)r->mlen / (r->blen + (int)r->n_ambi - n_gap + n_gapo);
-			const double div = 1.0 - ident;
-			char buf[16];
-			if (div == 0.0) buf[0] = '0', buf[1] = 0;
-			else snprintf(buf, 16, "%.4f", 1.0 - ident);
-			s += "\tde:f:"; s += buf;
-		}
+		gd_write_tags(s, *r);
 		// SA tag for the primary line when supplementary alignments exist, :565-590
 		if (r->parent == r->id && r->has_p && regs.size() > 1) {
 			int n_sa = 0;

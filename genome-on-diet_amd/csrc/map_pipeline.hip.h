@@ -931,3 +931,46 @@ extern "C" size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *ix, int
 	*out = buf;
 	return tot;
 }
+
+// All PAF lines of a batch (mm_write_paf3, LR/format.c:326-367, as step 2 prints them when MM_F_OUT_SAM is off: LR/map.c:2163-2185).
+// opt_flag: MM_F_OUT_CG adds the cg:Z: tag, MM_F_PAF_NO_HIT the lines of unmapped reads, MM_F_NO_PRINT_2ND drops secondary records.
+extern "C" size_t gdiet_hip_paf_batch(gdiet_ctx *ctx, const gdiet_index *ix, int n_reads, const char *const *qnames, const int32_t *lens,
+                                      const int32_t *n_regs, gdiet_reg_t *const *regs, int64_t opt_flag, char **out)
+{
+	if (!ctx || !ix || n_reads < 0 || !qnames || !lens || !n_regs || !regs || !out) return 0;
+	*out = nullptr;
+	const int CH = 512, n_ch = (n_reads + CH - 1) / CH;
+	std::vector<std::string> rec((size_t)n_ch);
+	gd_parallel_for(ctx, ctx->host_threads, n_ch, [&](int c) {
+		static thread_local std::vector<GdReg> v;
+		std::string &s = rec[c];
+		const int i1 = std::min(n_reads, (c + 1) * CH);
+		for (int i = c * CH; i < i1; ++i) {
+			const int nr = n_regs[i];
+			v.resize(nr > 0 ? nr : 0);
+			for (int j = 0; j < nr; ++j) {
+				const gdiet_reg_t &r = regs[i][j];
+				GdReg &g = v[j];
+				g.id = r.id, g.cnt = r.cnt, g.rid = r.rid, g.score = r.score, g.qs = r.qs, g.qe = r.qe, g.rs = r.rs, g.re = r.re, g.parent = r.parent, g.subsc = r.subsc;
+				g.mlen = r.mlen, g.blen = r.blen, g.mapq = r.mapq, g.rev = r.rev, g.sam_pri = r.sam_pri, g.dp_score = r.dp_score, g.dp_max = r.dp_max, g.n_ambi = r.n_ambi;
+				g.has_p = true, g.cigar.assign(r.cigar, r.cigar + r.n_cigar);
+			}
+			if (nr <= 0) {
+				if (opt_flag & GD_F_PAF_NO_HIT) gd_write_paf(s, ix->h.ref(), qnames[i], lens[i], v, -1, opt_flag), s += '\n';
+			} else
+				for (int j = 0; j < nr; ++j) {
+					if ((opt_flag & GD_F_NO_PRINT_2ND) && v[j].id != v[j].parent) continue;
+					gd_write_paf(s, ix->h.ref(), qnames[i], lens[i], v, j, opt_flag), s += '\n';
+				}
+		}
+	});
+	size_t tot = 0;
+	for (const std::string &r : rec) tot += r.size();
+	char *buf = (char *)malloc(tot + 1);
+	if (!buf) return 0;
+	size_t at = 0;
+	for (const std::string &r : rec) memcpy(buf + at, r.data(), r.size()), at += r.size();
+	buf[tot] = 0;
+	*out = buf;
+	return tot;
+}

@@ -85,6 +85,8 @@ def _bind(lib):
     lib.gdiet_hip_sam_record.restype = C.c_size_t
     lib.gdiet_hip_sam_batch.argtypes = [vp, vp, C.c_int, cpp, cpp, cpp, i32p, i32p, C.POINTER(C.POINTER(Reg)), C.c_int64, C.POINTER(vp)]
     lib.gdiet_hip_sam_batch.restype = C.c_size_t
+    lib.gdiet_hip_paf_batch.argtypes = [vp, vp, C.c_int, cpp, i32p, i32p, C.POINTER(C.POINTER(Reg)), C.c_int64, C.POINTER(vp)]
+    lib.gdiet_hip_paf_batch.restype = C.c_size_t
     lib._map_bound = True
 
 
@@ -306,6 +308,22 @@ class Mapper:
         out = C.c_void_p()
         m = self.lib.gdiet_hip_sam_batch(self.ctx._h, self._idx, n, qn, sq, ql, lens.ctypes.data_as(C.POINTER(C.c_int32)), res.n_regs, res.regs,
                                          self.opt.flag, C.byref(out))
+        try:
+            return C.string_at(out.value, m).decode() if out.value else ""
+        finally:
+            if out.value:
+                C.CDLL(None).free(C.c_void_p(out.value))
+
+    def paf_batch(self, res, reads, flag=0):
+        """every PAF line of a MapResult as one string (gdiet_hip_paf_batch); reads = [(qname, seq, ...), ...]; flag: extra MM_F_* bits
+        (0x20 = cg:Z: tag, 0x8000000 = lines for unmapped reads)"""
+        n = len(reads)
+        enc = lambda x: x if isinstance(x, bytes) else x.encode()
+        qn = (C.c_char_p * n)(*[enc(r[0]) for r in reads])
+        lens = np.array([len(r[1]) for r in reads], np.int32)
+        out = C.c_void_p()
+        m = self.lib.gdiet_hip_paf_batch(self.ctx._h, self._idx, n, qn, lens.ctypes.data_as(C.POINTER(C.c_int32)), res.n_regs, res.regs,
+                                         self.opt.flag | flag, C.byref(out))
         try:
             return C.string_at(out.value, m).decode() if out.value else ""
         finally:

@@ -265,6 +265,12 @@ size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *idx, int n_reads, 
                            const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
                            int64_t opt_flag, char **out);
 
+/* The same for PAF output: mm_write_paf3 (LR/format.c:326-367) as step 2 prints it when MM_F_OUT_SAM is off (LR/map.c:2163-2185).
+ * opt_flag: MM_F_OUT_CG (0x20, `-c`) adds the cg:Z: tag, MM_F_PAF_NO_HIT (0x8000000, --paf-no-hit) the lines of unmapped reads,
+ * MM_F_NO_PRINT_2ND drops secondary records, MM_F_QSTRAND is honoured.  *out is malloc'd; returns its length. */
+size_t gdiet_hip_paf_batch(gdiet_ctx *ctx, const gdiet_index *idx, int n_reads, const char *const *qnames, const int32_t *lens,
+                           const int32_t *n_regs, gdiet_reg_t *const *regs, int64_t opt_flag, char **out);
+
 /* Read input, step 0 of worker_pipeline (LR/map.c:2095-2131): FASTA / FASTQ, plain or gzip ("-" = stdin), one mini-batch per
  * call.  Replaces mm_bseq_open / mm_bseq_read3 / mm_bseq_close (LR/bseq.c:38-58, 80-121) with the same record grammar
  * (kseq_read, LR/kseq.h:191-232: multi-line records, names up to the first white space, the rest of the header as comment,

@@ -8,6 +8,7 @@
 
 What it makes, per kind of tests/fixture_io.py::SETS:
   <stem>.golden.sam.gz   the SAM body (no @ lines) of `gdiet_*_avx -t 4 <kind's .cmd> ref.fa reads.fq`
+  <stem>.golden.paf.gz   (kinds in PAF_KINDS) the PAF lines of the same reads: `-x` instead of `-ax`, plus `-c --paf-no-hit`
   <stem>.trace.gz        (kinds in TRACED) the --print-seeds stage trace of the same run (LR/map.c:1328-1338,1447-1459,
                          1592-1602,1670-1675,1808-1810,1858-1863), reduced to the lines the stage test compares
   fastx/*.expected.json  what the reference's parser returns for the awkward FASTA/FASTQ files of tests/fastx_inputs.py
@@ -24,7 +25,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from fixture_io import SETS, TRACED, TRACE_PREFIXES, cmd_of, reads_of  # noqa: E402
+from fixture_io import PAF_KINDS, SETS, TRACED, TRACE_PREFIXES, cmd_of, paf_cmd_of, reads_of  # noqa: E402
 
 REF = {"lr": os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx"), "sr": os.path.join(ROOT, "oracle", "_ref", "gdiet_sr_avx")}
 SV_SETS = {"hifi_sv": dict(n=150, seed=11, mean_len=9000), "ont_sv": dict(n=60, seed=12, mean_len=14000)}
@@ -75,7 +76,11 @@ def reference_run(kind, tmp):
         run = subprocess.run([REF[variant]] + cmd_of(kind) + ["--print-seeds", ref_fa, fq], capture_output=True, text=True, check=True)
         assert "".join(l + "\n" for l in run.stdout.split("\n") if l and not l.startswith("@")) == sam
         trace = "".join(l + "\n" for l in run.stderr.split("\n") if l.startswith(TRACE_PREFIXES))
-    return sam, trace
+    paf = None
+    if kind in PAF_KINDS:
+        run = subprocess.run([REF[variant], "-t", "4"] + paf_cmd_of(kind) + [ref_fa, fq], capture_output=True, text=True, check=True)
+        paf = "".join(l + "\n" for l in run.stdout.split("\n") if l)
+    return sam, trace, paf
 
 
 def fastx_expected(tmp):
@@ -117,8 +122,8 @@ def main():
                     print("%-40s %s" % ("fastx/" + fn, "ok" if same else ("WRITTEN" if a.write else "DIFFERS")))
                 continue
             d, stem, _ = SETS[kind]
-            sam, trace = reference_run(kind, tmp)
-            for suffix, text in ((".golden.sam.gz", sam), (".trace.gz", trace)):
+            sam, trace, paf = reference_run(kind, tmp)
+            for suffix, text in ((".golden.sam.gz", sam), (".trace.gz", trace), (".golden.paf.gz", paf)):
                 if text is None:
                     continue
                 p = os.path.join(d, stem + suffix)

@@ -63,7 +63,7 @@ int main(int argc, char **argv)
 	O.flag = GD_F_NO_PRINT_2ND * 0;
 	std::vector<const char *> pos;
 	const char *mmi_in = nullptr, *mmi_out = nullptr;
-	bool trace = false;
+	bool trace = false, out_sam = false;
 	int n_threads = 1;
 	bool preset_seen = false, sr_variant = false;
 	auto preset = [&](const char *p) -> bool {
@@ -92,15 +92,18 @@ int main(int argc, char **argv)
 					preset_seen = true;
 					if (!preset(p)) { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
 				}
-			} else if (a[0] == '-' && a.size() > 2 && a[1] == 'a' && a[2] == 'x') { // -ax <preset>
+			} else if (a[0] == '-' && a.size() > 2 && a[1] == 'a' && a[2] == 'x') { // -ax <preset> = -a -x <preset>
 				const char *p = argv[++i];
+				out_sam = true;
 				if (pass == 0) {
 					preset_seen = true;
 					if (!preset(p)) { fprintf(stderr, "unsupported preset %s\n", p); return 2; }
 				}
 			} else if (a == "-t") { v = argv[++i]; if (pass) n_threads = atoi(v) > 0 ? atoi(v) : 1; }
 			else if (a == "-o") ++i;
-			else if (a == "-a") {}
+			else if (a == "-a") { if (pass) out_sam = true; }
+			else if (a == "-c") { if (pass) O.flag |= GD_F_OUT_CG; }
+			else if (a == "--paf-no-hit") { if (pass) O.flag |= GD_F_PAF_NO_HIT; }
 			else if (a == "-k") { v = argv[++i]; if (pass) O.k = atoi(v); }
 			else if (a == "-w") { v = argv[++i]; if (pass) O.w = atoi(v); }
 			else if (a == "-Z") { v = argv[++i]; if (pass) Z = v; }
@@ -284,12 +287,14 @@ int main(int argc, char **argv)
 			for (size_t j = 0; j < regs.size(); ++j) {
 				if ((O.flag & GD_F_NO_PRINT_2ND) && regs[j].id != regs[j].parent) continue;
 				out.clear();
-				gd_write_sam(out, R, qn[ri].c_str(), seq.c_str(), qual, len, regs, (int)j, O.flag);
+				if (out_sam) gd_write_sam(out, R, qn[ri].c_str(), seq.c_str(), qual, len, regs, (int)j, O.flag);
+				else gd_write_paf(out, R, qn[ri].c_str(), len, regs, (int)j, O.flag);
 				sam_of[ri] += out, sam_of[ri] += '\n';
 			}
-		} else {
+		} else if (out_sam || (O.flag & GD_F_PAF_NO_HIT)) { // LR/map.c:2176-2179
 			out.clear();
-			gd_write_sam(out, R, qn[ri].c_str(), seq.c_str(), qual, len, regs, -1, O.flag);
+			if (out_sam) gd_write_sam(out, R, qn[ri].c_str(), seq.c_str(), qual, len, regs, -1, O.flag);
+			else gd_write_paf(out, R, qn[ri].c_str(), len, regs, -1, O.flag);
 			sam_of[ri] += out, sam_of[ri] += '\n';
 		}
 		if (terr) {

@@ -25,6 +25,25 @@ TRACED = ("hifi", "ont", "hifi_sv", "ont_sv", "sr")
 TRACE_PREFIXES = ("Final shift", "RS ", "SD\t", "VT\t", "AVT\t", "BE\t", "AL_SCORE", "CONQ", "CONT")
 
 
+# kinds with a committed PAF golden as well (<stem>.golden.paf.gz: the same command with -x instead of -ax, no -a, plus -c
+# --paf-no-hit: mm_write_paf3 with the cg:Z: tag and the unmapped lines)
+PAF_KINDS = ("hifi_sv", "sr")
+
+
+def paf_cmd_of(kind):
+    out = []
+    for tok in cmd_of(kind):
+        if tok == "-a":
+            continue
+        out.append("-x" if tok == "-ax" else tok)
+    return out + ["-c", "--paf-no-hit"]
+
+
+def golden_paf(kind):
+    d, stem, _ = SETS[kind]
+    return [l.rstrip("\n") for l in gzip.open(os.path.join(d, stem + ".golden.paf.gz"), "rt")]
+
+
 def read_fasta(path):
     names, seqs, cur = [], [], []
     op = gzip.open if path.endswith(".gz") else open

@@ -12,7 +12,7 @@ import subprocess
 import pytest
 
 from conftest import ROOT
-from fixture_io import SETS, cmd_of, golden_sam, reads_of
+from fixture_io import PAF_KINDS, SETS, cmd_of, golden_paf, golden_sam, paf_cmd_of, reads_of
 
 HIP_BIN = {v: os.path.join(ROOT, "oracle", "_ref", "gdiet_%s_hip" % v) for v in ("lr", "sr")}
 
@@ -75,3 +75,17 @@ def test_patched_reference_binary_prints_the_golden_sam(kind, tmp_path):
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert a == b, (a[:300], b[:300])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", list(PAF_KINDS))
+def test_patched_reference_binary_prints_the_golden_paf(kind, tmp_path):
+    """the same binary in PAF mode (-x, -c, --paf-no-hit): the records this library returns through the REFERENCE's mm_write_paf3"""
+    variant = "sr" if SETS[kind][2] == "sr" else "lr"
+    exe = HIP_BIN[variant]
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/gdiet_%s_hip not built (needs /root/reference at build time)" % variant)
+    ref_fa, fq = _inputs(kind, tmp_path)
+    r = subprocess.run([exe, "-t", "4"] + paf_cmd_of(kind) + [ref_fa, fq], capture_output=True, text=True, env=dict(os.environ, GDIET_HIP="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.rstrip("\n").split("\n") == golden_paf(kind)

@@ -5,7 +5,7 @@ import os
 
 import pytest
 
-from fixture_io import LR, OVERRIDES, SETS, golden_sam, read_fasta, read_fastq, reads_of
+from fixture_io import LR, OVERRIDES, PAF_KINDS, SETS, golden_paf, golden_sam, read_fasta, read_fastq, reads_of
 
 pytestmark = pytest.mark.gpu
 
@@ -33,6 +33,20 @@ def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
             assert gpu_ctx.last_kernel_mask() & 8
         if kind == "sr":  # 150 x 150, w = 150 boxes: the 16-lane kernel
             assert gpu_ctx.last_kernel_mask() & 4
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("kind", list(PAF_KINDS))
+def test_map_batch_matches_golden_paf(gpu_ctx, pkg, kind):
+    """gdiet_hip_paf_batch (mm_write_paf3) on the records of the GPU path: the reference's PAF lines, -c --paf-no-hit"""
+    base, stem, preset = SETS[kind]
+    names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+    reads = reads_of(kind)
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset=preset, **OVERRIDES.get(kind, {}))
+    try:
+        res = m.map([r[1] for r in reads])
+        assert m.paf_batch(res, reads, flag=0x20 | 0x8000000) == "".join(l + "\n" for l in golden_paf(kind))
     finally:
         m.close()
 

@@ -10,7 +10,7 @@ import subprocess
 import pytest
 
 from conftest import ROOT
-from fixture_io import LR, SETS, SR, TRACE_PREFIXES, cmd_of, golden_sam, reads_of, trace_of
+from fixture_io import LR, PAF_KINDS, SETS, SR, TRACE_PREFIXES, cmd_of, golden_paf, golden_sam, paf_cmd_of, reads_of, trace_of
 
 
 @pytest.fixture(scope="module")
@@ -45,6 +45,23 @@ def test_host_path_matches_golden_sam(host_driver, kind, tmp_path):
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert a == b, (a[:200], b[:200])
+
+
+@pytest.mark.parametrize("kind", list(PAF_KINDS))
+def test_host_path_matches_golden_paf(host_driver, kind, tmp_path):
+    """mm_write_paf3 restated (gd_write_paf): the PAF lines of the reference for the same reads -- -c (cg:Z: tag), --paf-no-hit (lines of
+    unmapped reads), supplementary / secondary records, the negative de:f values the reference prints for long insertions"""
+    exe, d = host_driver
+    base = SETS[kind][0]
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for name, seq, qual in reads_of(kind):
+            f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
+    out = subprocess.run([exe] + THREADS + paf_cmd_of(kind) + [os.path.join(d, os.path.basename(base), "ref.fa"), fq], capture_output=True, text=True, check=True)
+    got, want = out.stdout.rstrip("\n").split("\n"), golden_paf(kind)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a == b, (a[:300], b[:300])
 
 
 def test_host_path_matches_reference_binary_on_fresh_reads(host_driver, tmp_path):
