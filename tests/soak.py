@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""One-off soak comparison, larger than the committed fixtures (test infrastructure; not collected by pytest).
+
+    python tests/soak.py make     # CPU box: synthesise read sets, run the reference (oracle/_ref/gdiet_*_avx) -> build_ub/soak/*.sam.gz
+    python tests/soak.py check    # GPU box: map the same read sets through libgdiet_hip.so and compare every SAM line
+
+Read sets: SV-style HiFi and ONT reads (tools/synth.py --kind *_sv: linked candidates, concatenate_cigars, supplementary records),
+plain ONT reads long enough for the wide-band kernels (checkpointed form forced with GDIET_WIDE_CKPT=1), short reads of mixed lengths."""
+import gzip
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+OUT = os.path.join(ROOT, "build_ub", "soak")
+SETS = [  # name, variant, preset kind (fixture whose .cmd / reference is used), synth args, Mapper overrides
+    ("hifi_sv", "lr", "hifi_sv", ["--kind", "hifi_sv", "--n", "1500", "--seed", "101", "--mean-len", "9000"], {}),
+    ("ont_sv", "lr", "ont_sv", ["--kind", "ont_sv", "--n", "400", "--seed", "102", "--mean-len", "16000"], {"min_dp_max": 4000}),
+    ("ont", "lr", "ont_sv", ["--kind", "ont", "--n", "150", "--seed", "103"], {"min_dp_max": 4000}),
+    ("hifi", "lr", "hifi", ["--kind", "hifi", "--n", "1500", "--seed", "104"], {}),
+]
+
+
+def make():
+    from fixture_io import SETS as FX, cmd_of
+    os.makedirs(OUT, exist_ok=True)
+    for name, variant, kind, synth, _ in SETS:
+        d = FX[kind][0]
+        ref_fa = os.path.join(OUT, variant + "_ref.fa")
+        if not os.path.exists(ref_fa):
+            with gzip.open(os.path.join(d, "ref.fa.gz"), "rb") as f, open(ref_fa, "wb") as g:
+                g.write(f.read())
+        fq = os.path.join(OUT, name + ".fq")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "synth.py"), "reads", fq, "--ref", ref_fa] + synth)
+        exe = os.path.join(ROOT, "oracle", "_ref", "gdiet_%s_avx" % variant)
+        run = subprocess.run([exe, "-t", "8"] + cmd_of(kind) + [ref_fa, fq], capture_output=True, text=True, check=True)
+        body = "".join(l + "\n" for l in run.stdout.split("\n") if l and not l.startswith("@"))
+        with gzip.open(os.path.join(OUT, name + ".sam.gz"), "wt") as f:
+            f.write(body)
+        flags = {}
+        for l in body.split("\n"):
+            if l:
+                flags[l.split("\t")[1]] = flags.get(l.split("\t")[1], 0) + 1
+        print(name, "records", body.count("\n"), "flags", dict(sorted(flags.items(), key=lambda kv: int(kv[0]))))
+
+
+def check():
+    import torch  # noqa: F401
+    from conftest import load_pkg
+    from fixture_io import SETS as FX, read_fasta, read_fastq
+    pkg = load_pkg()
+    ctx = pkg.Context(0)
+    bad = 0
+    for name, variant, kind, _, over in SETS:
+        d, _, preset = FX[kind]
+        names, seqs = read_fasta(os.path.join(d, "ref.fa.gz"))
+        reads = read_fastq(os.path.join(OUT, name + ".fq.gz"))
+        want = gzip.open(os.path.join(OUT, name + ".sam.gz"), "rt").read()
+        m = pkg.Mapper(ctx, names, seqs, preset=preset, **over)
+        got = m.sam_batch(m.map([r[1] for r in reads]), reads)
+        m.close()
+
+        def norm(text):  # the reference's ms:i of reverse-strand records over reference Ns reads past its score matrix
+            out = []
+            for line in text.split("\n"):
+                f = line.split("\t")
+                if len(f) > 11 and int(f[1]) & 16 and "nn:i:0" not in f:
+                    f = [x for x in f if not x.startswith("ms:i:")]
+                out.append("\t".join(f))
+            return out
+        g, w = norm(got), norm(want)
+        n_diff = sum(1 for a, b in zip(g, w) if a != b) + abs(len(g) - len(w))
+        print(name, "reads", len(reads), "lines", len(w), "differing", n_diff, "kernel mask", ctx.last_kernel_mask())
+        if n_diff:
+            for a, b in zip(g, w):
+                if a != b:
+                    print("  got ", a[:200])
+                    print("  want", b[:200])
+                    break
+        bad += n_diff
+    ctx.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    {"make": make, "check": check}[sys.argv[1]]()
