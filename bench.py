@@ -157,15 +157,18 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_reference(names, contigs, rng, cores, which="largest"):
-    """the reference's own GDiet_avx on the host: index ONE contig with -d (outside the timing), then time mapping only.
-    which = "largest" (chr1-sized, the default: indexing the whole 3.1 Gbp reference with the reference binary takes minutes and
-    ~20 GB) | "smallest" | "whole".  The reads are drawn from the indexed contig(s) by the generator of the GPU leg."""
+def cpu_baseline_reference(names, contigs, rng, cores, which="whole", gpu_reads=None):
+    """the reference's own GDiet_avx on the host: build a .mmi with -d (outside the timing), then time mapping only.
+    which = "whole" (the default: the very reference the GPU leg maps against -- ~1 min of indexing and a 4 GB file for 3.1 Gbp --
+    and the FIRST 2048 READS OF THE GPU LEG's first batch) | "largest" (chr1-sized contig only, reads drawn from it) | "smallest"."""
     exe = os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")
     lens = [len(x) for x in contigs]
     sel = list(range(len(contigs))) if which == "whole" else [int(np.argmax(lens) if which == "largest" else np.argmin(lens))]
     sub = [contigs[i] for i in sel]
-    reads = synth_hifi_reads(rng, sub, 2048, only_contig=None if which == "whole" else 0)  # ~31 Mbases: seconds of wall time on the host's cores
+    if which == "whole" and gpu_reads:
+        reads = list(gpu_reads[:2048])
+    else:
+        reads = synth_hifi_reads(rng, sub, 2048, only_contig=None if which == "whole" else 0)  # ~31 Mbases: seconds of wall time on the host's cores
     hifi = ("-ax map-hifi -Z 10 -W 2 -i 0.2 -k 19 -w 19 -N 1 -r 1000 --vt_dis=650 --vt_nb_loc=5 --vt_df1=0.0106 --vt_df2=0.2 -s 400 "
             "--vt_cov 0.04 --max_min_gap=4000 --vt_f=0.04 --sort=merge --frag=no -F200,1 --secondary=yes -a").split()
     with tempfile.TemporaryDirectory() as d:
@@ -177,7 +180,8 @@ def cpu_baseline_reference(names, contigs, rng, cores, which="largest"):
             for nm, s in reads:
                 f.write(b"@" + nm.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
         t0 = time.time()
-        subprocess.run([exe, "-t", str(cores)] + hifi + ["-d", mmi, fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        subprocess.run([exe, "-t", str(cores)] + hifi + ["-d", mmi, fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=420)
+        os.unlink(fa)
         t_index = time.time() - t0
         # `cores` = the CPUs this container may use (cgroup quota / affinity, not the host's thread count).  The reference's thread
         # scaling is not perfect (its per-alignment 30 MB backtrace allocations serialise in the kernel), so the baseline is the BEST
@@ -199,9 +203,10 @@ def cpu_baseline_reference(names, contigs, rng, cores, which="largest"):
                 best = (v, t)
     what = {"largest": "the largest contig", "smallest": "the smallest contig", "whole": "the whole reference"}[which]
     return {"value": best[0], "unit": "mapped bases/s", "cores": best[1], "kind": "reference", "cpu_model": cpu_model(), "cpus_usable": cores,
-            "sample": "%d HiFi reads (%d bases, the GPU leg's generator) drawn from %s (%s, %d bp), GDiet_avx with a .mmi of it prebuilt in %.0f s "
+            "sample": "%d HiFi reads (%d bases, " % (len(reads), sum(len(s) for _, s in reads)) + ("the first reads of the GPU leg's first batch" if which == "whole" and gpu_reads else "the GPU leg's generator") +
+                      ") against %s (%s, %d bp), GDiet_avx with a .mmi of it prebuilt in %.0f s "
                       "(outside the timing), mapping wall time only (index load excluded); best of %s"
-                      % (len(reads), sum(len(s) for _, s in reads), what, "+".join(names[i] for i in sel) if which != "whole" else "%d contigs" % len(sel),
+                      % (what, "+".join(names[i] for i in sel) if which != "whole" else "%d contigs" % len(sel),
                          sum(lens[i] for i in sel), t_index, "; ".join(tried))}
 
 
@@ -260,7 +265,8 @@ def main():
                     help="N > 1: weak = every rank maps its own --batch reads per step (the contract's default); strong = ONE read set, each "
                          "batch cut into contiguous ranges of equal DP cost (read_ranges_by_cost), one per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-ref", default="largest", choices=["largest", "smallest", "whole"], help="what the reference binary indexes for the CPU baseline")
+    ap.add_argument("--cpu-baseline-ref", default="whole", choices=["whole", "largest", "smallest"],
+                    help="what the reference binary indexes for the CPU baseline (whole: the GPU leg's reference and reads; falls back to largest if that fails)")
     ap.add_argument("--no-upload-pass", action="store_true", help="skip the PCIe-inclusive pass (config.with_upload)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on a one-GPU box)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (default: LOCAL_RANK)")
@@ -492,7 +498,13 @@ def main():
             try:  # the reference binary itself where it travelled with the repo (and runs on this host's CPU) ...
                 if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "gdiet_lr_avx")):
                     raise FileNotFoundError("oracle/_ref/gdiet_lr_avx")
-                out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), pkg_cpus, args.cpu_baseline_ref)
+                try:
+                    out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), pkg_cpus, args.cpu_baseline_ref, batches[0][1])
+                except Exception as ex_whole:  # e.g. no room for the 4 GB index file: the chr1-sized form
+                    if args.cpu_baseline_ref != "whole":
+                        raise
+                    out["cpu_baseline"] = cpu_baseline_reference(names, contigs, np.random.default_rng(99), pkg_cpus, "largest")
+                    out["cpu_baseline"]["sample"] += " (whole-reference baseline failed: %r)" % (ex_whole,)
             except Exception as ex:  # ... else the DP stage of the oracle port; the baseline must never take the benchmark line down
                 try:
                     out["cpu_baseline"] = cpu_baseline_port(port_reads)

@@ -275,3 +275,26 @@ def test_wide_band_kernels_match_oracle(pkg, oracle, monkeypatch, two_waves):
             assert np.array_equal(cg[i], o["cigar"]), (i, len(qs[i]), len(ts[i]), ws[i])
     finally:
         ctx.close()
+
+
+def test_checkpointed_kernel_on_a_very_long_alignment(pkg, oracle, monkeypatch):
+    """one 120 kbp x 120 kbp ONT-like pair (w = 1300: 235 chunks of 1024 anti-diagonals, 319 MB of backtrace in the reference's layout,
+    9.6 MB here) through the checkpointed wide-band kernel against the oracle, plus its consistency with the stored-backtrace kernel"""
+    gdo, lib = oracle
+    rng = np.random.default_rng(77)
+    q, t = gdo.make_pair(rng, 120000, 0.03, 0.02, 0.02)
+    q2, t2 = gdo.make_pair(rng, 30000, 0.03, 0.02, 0.02)
+    a, b, q_, e, qq2, e2 = gdo.PRESETS["ont"]
+    o = gdo.oracle_extd2(lib, q, t, gdo.score_matrix(a, b), q_, e, qq2, e2, 1300, flag=gdo.EZ_APPROX_MAX | gdo.EZ_AVX512_SC)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GDIET_WIDE_CKPT", mode)
+        ctx = pkg.Context(0)
+        try:
+            sc, cg = ctx.ksw_extd2_batch([q, q2], [t, t2], 1300, pkg.KswScore.from_preset("ont"))
+            assert ctx.last_kernel_mask() & 8
+            res[mode] = (list(sc), [c.copy() for c in cg])
+        finally:
+            ctx.close()
+    assert res["1"][0][0] == o["score"] and np.array_equal(res["1"][1][0], o["cigar"])
+    assert res["1"][0] == res["0"][0] and all(np.array_equal(x, y) for x, y in zip(res["1"][1], res["0"][1]))
