@@ -156,7 +156,10 @@ int gdiet_hip_last_dp_work(const gdiet_ctx *ctx, uint64_t *cells, uint64_t *alg_
 typedef struct gdiet_index gdiet_index;
 
 /* Build the index from nt ASCII sequences with this library's own builder (same minimizers, same position order
- * as mm_idx_gen of GDiet_avx: LR/index.c:306-412, LR/sketch.c:156/1577) and upload it.  pattern/pattern_len = -Z/-W. */
+ * as mm_idx_gen of GDiet_avx: LR/index.c:306-412, LR/sketch.c:156/1577) and upload it.  pattern/pattern_len = -Z/-W.
+ * Limits, refused with GDIET_E_PARAM: 1 <= k <= 28 as in the reference (LR/main.c), and 1 <= w <= 64 -- the reference accepts
+ * w < 256; the winnowing windows of the sketch kernels live in registers / LDS sized for 64 (every preset uses w <= 19).  For
+ * w in {2, 3, 5, 6} the reference's own scalar and AVX-512 sketches disagree; this library follows the scalar one. */
 int gdiet_hip_index_build(gdiet_ctx *ctx, gdiet_index **idx, int n_seq, const char *const *names,
                           const char *const *seqs, const uint32_t *lens, int k, int w, const char *pattern,
                           int pattern_len, int n_threads);
