@@ -257,8 +257,6 @@ static inline bool gd_index_read_mmi(GdIndex &h, const char *path, const GdPatte
 	return true;
 }
 
-// Writes an index the reference's mm_idx_load accepts (same records as mm_idx_dump; the order of the keys inside a bucket is
-// khash-internal in the reference's files and carries no meaning: mm_idx_load re-inserts them one by one).
 // khash's slot placement (LR/khash.h:199-330), emulated for the one call sequence the index builder makes: kh_init, kh_resize(n_keys),
 // then kh_put of every key of the bucket in ascending order (LR/index.c:216-264, worker_post).  mm_idx_dump writes a bucket's entries
 // in SLOT order (LR/index.c:497-516), so a byte-identical .mmi needs the slots, not just the set of keys.  hash = key >> 1 (idx_hash,

@@ -100,6 +100,7 @@ extern "C" int gdiet_hip_index_import(gdiet_ctx *ctx, gdiet_index **out, int k, 
 	(void)hipSetDevice(ctx->device);
 	GdPattern P;
 	if (!gd_pattern_init(P, pattern, pattern_len)) { ctx->err = "bad pattern"; return GDIET_E_PARAM; }
+	if (w <= 0 || w > GDM_MAX_W || k <= 0 || k > 28) { ctx->err = "k must be in [1,28] and w in [1,64]"; return GDIET_E_PARAM; }
 	gdiet_index *ix = new gdiet_index();
 	gd_index_from_flat(ix->h, k, w, P, n_seq, names, lens, offsets, S, n_keys, keys, cnt, pos);
 	int rc = gd_index_upload(ctx, ix);
@@ -146,6 +147,11 @@ extern "C" int gdiet_hip_index_load_mmi(gdiet_ctx *ctx, gdiet_index **out, const
 	if (!gd_pattern_init(P, pattern, pattern_len)) { ctx->err = "bad pattern"; return GDIET_E_PARAM; }
 	gdiet_index *ix = new gdiet_index();
 	if (!gd_index_read_mmi(ix->h, path, P, ctx->err)) { delete ix; return GDIET_E_PARAM; }
+	if (ix->h.w <= 0 || ix->h.w > GDM_MAX_W || ix->h.k <= 0 || ix->h.k > 28) { // the sketch kernels' windows are sized for these (gdiet_hip_index_build)
+		ctx->err = std::string(path) + ": k must be in [1,28] and w in [1,64]";
+		delete ix;
+		return GDIET_E_PARAM;
+	}
 	int rc = gd_index_upload(ctx, ix);
 	if (rc) { delete ix; return rc; }
 	*out = ix;

@@ -174,6 +174,15 @@ def test_mmi_index_files(gpu_ctx, pkg, tmp_path):
         m3.close()
     with pytest.raises(pkg.GdietError):
         pkg.Mapper.from_mmi(gpu_ctx, os.path.join(SR, "sr.cmd"), names, [len(s) for s in seqs], preset="sr")  # not an index file
+    # an index whose window size exceeds what the sketch kernels hold (w = 100: header word 0) is refused, not mapped with
+    big = str(tmp_path / "w100.mmi")
+    raw = bytearray(open(theirs, "rb").read())
+    raw[4:8] = (100).to_bytes(4, "little")
+    open(big, "wb").write(bytes(raw))
+    with pytest.raises(pkg.GdietError):
+        pkg.Mapper.from_mmi(gpu_ctx, big, names, [len(s) for s in seqs], preset="sr")
+    with pytest.raises(pkg.GdietError):
+        pkg.Mapper(gpu_ctx, names, seqs, preset="sr", w=65)
 
 
 @pytest.mark.parametrize("kind", ["hifi", "ont", "sr"])
