@@ -64,7 +64,7 @@ static inline bool gd_wave_scoring_ok(const KswConst &C)
 
 static inline bool gd_wave_supported(int qlen, int tlen, int w, int lanes)
 {
-	return gd_wave_geometry_ok(qlen, tlen, w, lanes);
+	return qlen + tlen < (1 << 21) && gd_wave_geometry_ok(qlen, tlen, w, lanes); // (a row's offset into the backtrace is a 32-bit quantity)
 }
 
 // LANES == 64: one alignment per wavefront (task_ids[slot]).
@@ -118,6 +118,16 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 #pragma unroll
 	for (int g = 0; g < NG; ++g) qg[g] = gdw_uniform_ptr(query, g * LANES);
 
+	// The 16 backtrace bytes of a lane.  64-lane form: the alignment's backtrace is a buffer resource (base in SGPRs), the row a scalar
+	// offset and the lane a constant 32-bit vector offset, so the row loop carries no 64-bit vector address (2-3 VGPRs of the 96).
+	typedef u32 gdw_u32x4 __attribute__((ext_vector_type(4)));
+	__amdgpu_buffer_rsrc_t bt_rsrc = __builtin_amdgcn_make_buffer_rsrc(bt + (LANES == 64 ? Tp->bt_off : 0), 0, (int)0xffffffffu, 0x00020000);
+	auto store_row = [&](const int r, const u32 out[4]) __attribute__((always_inline)) {
+		if (LANES == 64) {
+			const gdw_u32x4 d = {out[0], out[1], out[2], out[3]};
+			__builtin_amdgcn_raw_buffer_store_b128(d, bt_rsrc, lane * 16, r * (LANES * 16), 0); // (qlen + tlen < 2^21: gd_wave_supported)
+		} else if (live) *reinterpret_cast<uint4 *>(p + (size_t)r * (LANES * 16)) = make_uint4(out[0], out[1], out[2], out[3]);
+	};
 	WaveLane L;
 	gdw_load_block(L, K, sub, 0, query, qlen, target, tlen);
 	bool any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0; // wave-uniform: does any lane hold a target N?
@@ -162,7 +172,7 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 		if (L.blk <= W.en_) {
 			u32 out[4];
 			gdw_compute<DUAL>(L, K, W, pX, pV, pX2, out);
-			if (LANES == 64 || live) *reinterpret_cast<uint4 *>(p + (size_t)r * (LANES * 16)) = make_uint4(out[0], out[1], out[2], out[3]);
+			store_row(r, out);
 		}
 		// (5) score trackers
 		if (!STEADY && r == 0) L.R = gdw_lo(L.V[0]) - K.B1 - K.qe8;
@@ -180,12 +190,70 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 		}
 		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
 	};
+	// The rows [rA, rS) in the middle of a long alignment come in pairs: on the first (r - w + 1 even) st0 has just moved up by one
+	// cell, on the second en0 has; both are pure functions of m = (r - w + 1) >> 1 there (gdw_steady_rows).  Written out as a pair,
+	// the band limits need no min / max, the selectors are rebuilt only when they change, and what can happen only on one of the two
+	// rows (a block retiring; a block entering the band) is tested only there: -40 scalar and -10 vector instructions per row.
+	const int nblkA = (w - 1 + 16) >> 4, nblkB = (w + 16) >> 4; // blocks whose scores are rewritten on the first / second row of a pair
+	auto pair_row = [&](const int r, const int m, auto a_tag) __attribute__((always_inline)) {
+		constexpr bool ROW_A = decltype(a_tag)::value;
+		WaveRow W;
+		W.r = r, W.st0 = m, W.en0 = ROW_A ? m + w - 1 : m + w;
+		W.st_ = m >> 4, W.en_ = W.en0 >> 4;
+		W.up = m + ((ROW_A ? nblkA : nblkB) << 4);
+		const int advanced = ROW_A && (m & 15) == 0;
+		const int pst_ = W.st_ - advanced; // st_ of the row before
+		W.use_array = advanced, W.v1key = K.key_open, W.set_tr = 0, W.ukey = 0;
+		const u32 pX = gdw_ror1<LANES>(L.X[7]), pV = gdw_ror1<LANES>(L.V[7]), pX2 = gdw_ror1<LANES>(L.X2[7]), pQ = gdw_ror1<LANES>(L.Qc[3]);
+		{
+			const int j = r - (pst_ << 4);
+			u32 seam = gdw_seam_byte(qg[0], qlen, j);
+#pragma unroll
+			for (int g = 1; g < NG; ++g) {
+				const u32 sg = gdw_seam_byte(qg[g], qlen, j);
+				seam = row == g ? sg : seam;
+			}
+			gdw_shift_query(L, pQ, L.blk == pst_, seam);
+		}
+		if (advanced) {
+			if (L.blk < W.st_) gdw_load_block(L, K, L.blk + LANES, r, query, qlen, target, tlen);
+			any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0;
+		}
+		if (ROW_A || nblkA != nblkB) {
+			u32 lo[4], hi[4];
+			gdw_sel_uniform(m & 15, lo, hi);
+			gdw_pick_sel(L, W.st_, W.up >> 4, (W.up >> 4) - W.st_ >= LANES - 1, lo, hi, W.m_first);
+			W.m_first_valid = 1; // the lane mask "holds the lowest block", for the boundary scalars in gdw_compute
+		}
+		gdw_update_scores(L, K, any_tn);
+		if (L.blk <= W.en_) {
+			u32 out[4];
+			gdw_compute<DUAL>(L, K, W, pX, pV, pX2, out);
+			store_row(r, out);
+		}
+		L.R += gdw_lo(L.V[0]) - K.B1;
+		if (!ROW_A && (W.en0 & 15) == 0) {
+			const int h = (int)gdw_ror1<LANES>((u32)gdw_track_handoff(L));
+			if (L.blk == W.en_) L.R = h + gdw_lo(L.U[0]);
+		}
+	};
 	{
 		// steady rows: (en0 | 15) < r and st0 >= 16 hold from r = w + 48 on (en0 <= (r + w) / 2, st0 >= (r - w + 1) / 2); the last target
 		// column is reached at r = max(tlen - 1, 2 (tlen - 1) - w)
-		const int rA = w + 48, t1_ = tlen - 1, rB0 = 2 * t1_ - w, rB = rB0 > t1_ ? rB0 : t1_;
+		int rA, rS;
+		gdw_steady_rows(qlen, tlen, w, rA, rS);
+		const int t1_ = tlen - 1, rB0 = 2 * t1_ - w, rB = rB0 > t1_ ? rB0 : t1_;
 		int r = 0;
 		for (; r <= rend && r < rA; ++r) dp_row(r, std::false_type());
+		if (r == rA && rS > rA) {
+			int m = (rA - w + 1) >> 1;
+			for (; r < rS; r += 2, ++m) {
+				pair_row(r, m, std::true_type());
+				pair_row(r + 1, m, std::false_type());
+			}
+			--m; // the band of the last row, for the rows that follow
+			prev_st_ = m >> 4, prev_st0 = m, prev_up = m + (nblkB << 4), prev_en0 = m + w;
+		}
 		for (; r <= rend && r < rB; ++r) dp_row(r, std::true_type());
 		for (; r <= rend; ++r) dp_row(r, std::false_type());
 	}

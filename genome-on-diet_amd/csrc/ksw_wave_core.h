@@ -190,6 +190,8 @@ struct WaveRow {
 	int v1key;       // otherwise: key of v1 (x1/x21 are always the no-continuation keys then)
 	int set_tr;      // en >= r: cell t == r gets u/y/y2 reset (:160-163)
 	int ukey;        // key of u[r] for that reset
+	int m_first_valid = 0; // the caller already holds the lane mask "this lane's block is st_" (paired rows)
+	u32 m_first = 0;
 };
 
 // selectors for the score blend of one lane: cells [st0, up) are rewritten (:166-180)
@@ -206,6 +208,40 @@ GDW_HD void gdw_make_sel(WaveLane &L, int st0, int up)
 		const u32 spread = (n * 0x00204081u) & 0x01010101u; // bit i of n -> bit 0 of byte i
 		L.SEL[g] = 0x03020100u + (spread << 2);
 	}
+}
+
+// The same selectors for the rows in the middle of a long alignment, where they depend on the lane only through its role: with
+// d0 = st0 & 15, the lane of the lowest block st_ rewrites its cells >= d0, the lane of block top = up >> 4 its cells < d0 (up and
+// st0 are congruent mod 16), the blocks between them all 16 cells and the blocks above top none.  The two selector sets are
+// wave-uniform (scalar unit); a lane only picks.
+GDW_HD void gdw_sel_uniform(int d0, u32 lo[4], u32 hi[4])
+{
+	const uint64_t C = 0x0404040404040404ull; // byte c of the 16-byte mask (f1:f0) = 4 iff cell c >= d0
+	const uint64_t f0 = d0 < 8 ? C << (8 * d0) : 0ull, f1 = d0 < 8 ? C : C << (8 * (d0 - 8));
+	lo[0] = 0x03020100u + (u32)f0, lo[1] = 0x03020100u + (u32)(f0 >> 32), lo[2] = 0x03020100u + (u32)f1, lo[3] = 0x03020100u + (u32)(f1 >> 32);
+#pragma unroll
+	for (int g = 0; g < 4; ++g) hi[g] = 0x0a080604u - lo[g]; // 0x03020100 + (0x04040404 - mask)
+}
+// (a select between two scalar values costs a copy into a vector register plus the select -- one scalar operand per instruction --
+// so the picks are v_bfi_b32 with the scalar value as data and a 0 / ~0 lane mask; all_inside: no lane holds a block above top)
+#if defined(__HIP_DEVICE_COMPILE__)
+GDW_HD u32 gdw_bfi_s(u32 mask, u32 a_uniform, u32 b)
+{
+	u32 d;
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "s"(a_uniform), "v"(b));
+	return d;
+}
+#else
+GDW_HD u32 gdw_bfi_s(u32 mask, u32 a_uniform, u32 b) { return gdw_bfi(mask, a_uniform, b); }
+#endif
+GDW_HD void gdw_pick_sel(WaveLane &L, int st_, int top, bool all_inside, const u32 lo[4], const u32 hi[4], u32 &m_lo)
+{
+	m_lo = L.blk == st_ ? ~0u : 0u;
+	const u32 m_top = L.blk == top ? ~0u : 0u;
+	u32 base = 0x07060504u;
+	if (!all_inside) base = L.blk < top ? 0x07060504u : 0x03020100u;
+#pragma unroll
+	for (int g = 0; g < 4; ++g) L.SEL[g] = gdw_bfi_s(m_lo, lo[g], gdw_bfi_s(m_top, hi[g], base));
 }
 
 // advance the query window by one anti-diagonal: cell i now faces what cell i-1 faced.  Cell 0 takes the byte that cell 15
@@ -266,12 +302,12 @@ GDW_HD void gdw_reset_tr(WaveLane &L, const WaveK &K, const WaveRow &W)
 template <bool DUAL = true>
 GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u32 pV, u32 pX2, u32 bt[4])
 {
-	u32 inX = gdw_alignbit(L.X[7], pX, 16), inV = gdw_alignbit(L.V[7], pV, 16), inX2 = DUAL ? gdw_alignbit(L.X2[7], pX2, 16) : 0u;
-	if (L.blk == W.st_ && !W.use_array) { // first computed block: boundary scalars x1, v1, x21 (:149-159)
-		inX = (inX & 0xffff0000u) | (K.cx & 0xffffu);
-		inV = (inV & 0xffff0000u) | ((u32)W.v1key & 0xffffu);
-		if (DUAL) inX2 = (inX2 & 0xffff0000u) | (K.cx2 & 0xffffu);
+	if (!W.use_array) { // first computed block: boundary scalars x1, v1, x21 (:149-159) instead of what the lane below handed over
+		const u32 first = W.m_first_valid ? W.m_first : (L.blk == W.st_ ? ~0u : 0u); // (only the upper halves of the incoming dwords are looked at)
+		pX = gdw_bfi_s(first, K.cx, pX), pV = gdw_bfi_s(first, gdw_pack2(W.v1key), pV);
+		if (DUAL) pX2 = gdw_bfi_s(first, K.cx2, pX2);
 	}
+	const u32 inX = gdw_alignbit(L.X[7], pX, 16), inV = gdw_alignbit(L.V[7], pV, 16), inX2 = DUAL ? gdw_alignbit(L.X2[7], pX2, 16) : 0u;
 	u32 zk_hi = 0;
 #pragma unroll
 	for (int k = 7; k >= 0; --k) {
@@ -284,7 +320,7 @@ GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u
 			zk = pk_max(zk, pk_add(pk_max(a2, b2), K.c2));
 		}
 		const u32 z8 = pk_min(zk & 0xfff8fff8u, K.zmax);
-		const u32 nU = pk_sub(z8, vin), nV = pk_sub(z8, L.U[k]);
+		const u32 nV = pk_sub(z8, L.U[k]), nU = pk_sub(z8, vin); // (this order: U[k] is last read by nV, so nU can take its register)
 		const u32 tE = pk_sub(z8, K.te);
 		L.X[k] = pk_max(pk_sub(a, tE), K.cx), L.Y[k] = pk_max(pk_sub(b, tE), K.cy);
 		if (DUAL) {
@@ -306,6 +342,20 @@ GDW_HD void gdw_compute(WaveLane &L, const WaveK &K, const WaveRow &W, u32 pX, u
 			bt[k >> 1] = gdw_bfi_u(0xf0f0f0f0u, f, gdw_perm(zk_hi, zk, 0x06020400u));
 		}
 	}
+}
+
+// Rows [rA, rS), rS - rA even, of a long alignment for which, with m = (r - w + 1) >> 1:
+//   r - w + 1 even:  st0 = m, en0 = m + w - 1        r - w + 1 odd:  st0 = m, en0 = m + w
+// and neither the first block, the cell t == r, nor the last target column is involved (st0 >= 16, (en0 | 15) < r, en0 < tlen - 1):
+//   st0 = max(0, r - qlen + 1, (r - w + 1) >> 1) is its last term iff r <= 2 qlen - w - 2 (and r >= w - 1),
+//   en0 = min(tlen - 1, r, (r + w) >> 1) is its last term, and below tlen - 1, iff r < 2 (tlen - 1) - w (and r >= w).
+GDW_HD void gdw_steady_rows(int qlen, int tlen, int w, int &rA, int &rS)
+{
+	rA = w + 48;
+	if ((rA - w + 1) & 1) ++rA;
+	const int a = 2 * (tlen - 1) - w, b = 2 * qlen - w - 1;
+	rS = a < b ? a : b;
+	rS = rS > rA ? rA + ((rS - rA) & ~1) : rA;
 }
 
 // ---- score tracking ----------------------------------------------------------------------------------------

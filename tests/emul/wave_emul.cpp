@@ -30,6 +30,9 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 	std::vector<uint8_t> bt((size_t)(rend + 1) * LANES * 16, 0xEE);
 	for (int l = 0; l < LANES; ++l) gdw_load_block(L[l], K, l, 0, query, qlen, target, tlen);
 	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
+	int rA, rS; // the paired rows in the middle of a long alignment (the device's pair_row): band limits, selectors and the events of a row from m alone
+	gdw_steady_rows(qlen, tlen, w, rA, rS);
+	const int nblkA = (w - 1 + 16) >> 4, nblkB = (w + 16) >> 4;
 	for (int r = 0; r <= rend; ++r) {
 		WaveRow W;
 		W.r = r;
@@ -37,11 +40,22 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 		if (W.st0 > W.en0) { fprintf(stderr, "empty band in wave kernel\n"); exit(2); }
 		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
 		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
-		const int advanced = W.st_ > prev_st_;
+		int advanced = W.st_ > prev_st_;
 		W.use_array = advanced;
 		W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
 		W.set_tr = (W.en0 | 15) >= r;
 		W.ukey = gdw_edge_key(K, r);
+		const bool paired = r >= rA && r < rS, row_a = paired && ((r - rA) & 1) == 0;
+		if (paired) { // what pair_row derives from m must be what the generic row computes
+			const int m = (r - w + 1) >> 1;
+			WaveRow P;
+			P.r = r, P.st0 = m, P.en0 = row_a ? m + w - 1 : m + w, P.st_ = m >> 4, P.en_ = P.en0 >> 4, P.up = m + ((row_a ? nblkA : nblkB) << 4);
+			const int adv = row_a && (m & 15) == 0;
+			P.use_array = adv, P.v1key = K.key_open, P.set_tr = 0, P.ukey = 0;
+			if (((r - w + 1) & 1) != (row_a ? 0 : 1) || P.st0 != W.st0 || P.en0 != W.en0 || P.up != W.up || adv != advanced || P.st_ - adv != prev_st_ || W.set_tr || W.v1key != K.key_open ||
+			    W.en0 == tlen - 1 || (row_a && W.en0 != prev_en0) || (!row_a && W.st0 != prev_st0)) { fprintf(stderr, "paired row %d: band bookkeeping differs\n", r); exit(2); }
+			W = P, advanced = adv;
+		}
 		// (1) cross-lane exchange of row r-1 values (DPP wave_ror:1 on the GPU), before anything is modified
 		std::vector<u32> pX(LANES), pV(LANES), pX2(LANES), pQ(LANES);
 		for (int l = 0; l < LANES; ++l) {
@@ -63,7 +77,18 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 		for (int l = 0; l < LANES; ++l) any_tn |= L[l].tn != 0;
 		for (int l = 0; l < LANES; ++l) {
 			if (W.set_tr) gdw_reset_tr(L[l], K, W);
-			if (remask) gdw_make_sel(L[l], W.st0, W.up);
+			if (paired) {
+				if (row_a || nblkA != nblkB) {
+					u32 lo[4], hi[4], want[4];
+					gdw_sel_uniform(W.st0 & 15, lo, hi);
+					u32 m_lo;
+					gdw_pick_sel(L[l], W.st_, W.up >> 4, (W.up >> 4) - W.st_ >= LANES - 1, lo, hi, m_lo);
+					if (m_lo != (L[l].blk == W.st_ ? ~0u : 0u)) { fprintf(stderr, "lane mask\n"); exit(2); }
+					memcpy(want, L[l].SEL, 16);
+					gdw_make_sel(L[l], W.st0, W.up);
+					if (memcmp(want, L[l].SEL, 16)) { fprintf(stderr, "paired row %d lane %d: selectors differ\n", r, l); exit(2); }
+				} else if (remask) { fprintf(stderr, "paired row %d: selectors change on a second row\n", r); exit(2); }
+			} else if (remask) gdw_make_sel(L[l], W.st0, W.up);
 			gdw_update_scores(L[l], K, any_tn);
 		}
 		// (4) the DP cells of the active lanes
@@ -77,6 +102,7 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 		// (5) score trackers
 		if (r == 0) L[0].R = gdw_lo(L[0].V[0]) - K.B1 - K.qe8;
 		else for (int l = 0; l < LANES; ++l) L[l].R += gdw_lo(L[l].V[0]) - K.B1;
+		if (paired && row_a && W.en0 != prev_en0) { fprintf(stderr, "paired row %d: en0 moved on a first row\n", r); exit(2); }
 		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 15) == 0) {
 			const int m = W.en0 >> 4;
 			const int h = gdw_track_handoff(L[(m - 1) % LANES]);
