@@ -222,7 +222,7 @@ __device__ __forceinline__ void gd_bt_wave_walk(const KswTask &T, int tid, const
 
 // The same walk in resumable form, for a backtrace that exists one chunk of anti-diagonals at a time (ksw_extd2_wave128c_kernel):
 // gd_walk_rows consumes cells while their anti-diagonal is >= r0 (rows of `chunk`, row r at (r - r0) * row_bytes, the layout of
-// the two-blocks-per-lane kernel) and returns with its state, to be called again on the chunk below.
+// the two-blocks-per-lane kernel or of the cone) and returns with its state, to be called again on the chunk below.
 struct GdWalk { int i, j, state, have, nc; uint32_t last; };
 __device__ __forceinline__ void gd_walk_init(GdWalk &W, int qlen, int tlen) { W.i = tlen - 1, W.j = qlen - 1, W.state = 0, W.have = 0, W.nc = 0, W.last = 0; }
 __device__ __forceinline__ void gd_walk_push(GdWalk &W, uint32_t *cg, int cap, int lane, uint32_t op, uint32_t len)
@@ -233,12 +233,13 @@ __device__ __forceinline__ void gd_walk_push(GdWalk &W, uint32_t *cg, int cap, i
 		W.last = len << 4 | op, W.have = 1;
 	}
 }
+// cone_stride > 0: rows of `chunk` hold the 64 blocks [cone_b0, cone_b0 + 63] (gdw_cone_row) instead of the blocks of the band
 __device__ __forceinline__ void gd_walk_rows(GdWalk &W, const KswTask &T, const uint8_t *__restrict__ chunk, int r0, int qlen, int tlen, int w,
-                                             uint32_t *__restrict__ cigar, int lane)
+                                             uint32_t *__restrict__ cigar, int lane, int cone_stride = 0, int cone_b0 = 0)
 {
 	uint32_t *cg = cigar + T.cig_off;
 	const int cap = __builtin_amdgcn_readfirstlane(T.cig_cap);
-	const size_t row_bytes = (size_t)__builtin_amdgcn_readfirstlane(T.row_bytes);
+	const size_t row_bytes = cone_stride > 0 ? (size_t)cone_stride : (size_t)__builtin_amdgcn_readfirstlane(T.row_bytes);
 	while (W.i >= 0 && W.j >= 0 && W.i + W.j >= r0) {
 		const int i0 = W.i, j0 = W.j;
 		const int ik = i0 - lane, jk = j0 - lane;
@@ -253,7 +254,8 @@ __device__ __forceinline__ void gd_walk_rows(GdWalk &W, const KswTask &T, const 
 			if (ik > off_end) fs = 1;
 			if (fs < 0) {
 				const int c = ik & 15, g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
-				pf = chunk[(size_t)(r - r0) * row_bytes + (size_t)(((ik >> 4) - (off >> 4)) << 4) + (g << 2) + h];
+				const int b = (ik >> 4) - (cone_stride > 0 ? cone_b0 : off >> 4);
+				pf = chunk[(size_t)(r - r0) * row_bytes + (size_t)(b << 4) + (g << 2) + h];
 			}
 		}
 		for (int k = 0; k < 64; ++k) {

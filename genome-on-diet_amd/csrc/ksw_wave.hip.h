@@ -432,15 +432,15 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *_
 // A 50 kbp ONT alignment writes 134 MB of backtrace, so only ~1 500 fit the HBM at once -- fewer than the GPU has wavefront
 // slots, and the rate is bound by how many are in flight.  Here the first pass stores no backtrace at all, only a snapshot of the
 // lanes' registers every GD_CK_ROWS anti-diagonals (35 KB each); the second pass walks the alignment back chunk by chunk from the
-// end: restore the snapshot of the chunk, recompute its rows into a GD_CK_ROWS-row buffer (1.4 MB), let the walk consume them, go
+// end: restore the snapshot of the chunk, recompute its rows (the cone of the walk only, below) into a GD_CK_ROWS-row buffer (1 MB), let the walk consume them, go
 // on with the chunk below.  ~1.85x the arithmetic (the first pass drops the flag / direction bytes), 4.9 MB instead of 134 MB per
 // alignment: thousands in flight.  Rows, scores and CIGARs are those of the kernel above (same row function, same walk).
-#define GD_CK_ROWS 1024
+#define GD_CK_ROWS 960  // <= 62 * 16: the cells a walk can visit inside one chunk, and all they depend on, span at most 64 blocks (gdw_cone_row)
 #define GD_CK_REGS 136 // dwords per lane per snapshot: 2 x (48 state + 16 Sb/Tb/Qc/SEL + tn, blk, R) + Rf + pad
-static inline __host__ __device__ size_t gd_ck_bytes(int qlen, int tlen, int row_bytes)
+static inline __host__ __device__ size_t gd_ck_bytes(int qlen, int tlen, int /*row_bytes*/)
 {
 	const size_t rows = (size_t)qlen + tlen - 1, n_ck = (rows + GD_CK_ROWS - 1) / GD_CK_ROWS;
-	return n_ck * (size_t)GD_CK_REGS * 64 * 4 + (size_t)GD_CK_ROWS * (size_t)row_bytes;
+	return n_ck * (size_t)GD_CK_REGS * 64 * 4 + (size_t)GD_CK_ROWS * 1024; // snapshots + one chunk of 64-block rows
 }
 
 __device__ __forceinline__ void gdw_lane_save(const WaveLane &L, u32 *d) // d: this lane's column of the snapshot, stride 64 dwords
@@ -458,6 +458,53 @@ __device__ __forceinline__ void gdw_lane_load(WaveLane &L, const u32 *d)
 #pragma unroll
 	for (int g = 0; g < 4; ++g) L.Sb[g] = d[(48 + g) * 64], L.Tb[g] = d[(52 + g) * 64], L.Qc[g] = d[(56 + g) * 64], L.SEL[g] = d[(60 + g) * 64];
 	L.tn = d[64 * 64], L.blk = (int32_t)d[65 * 64], L.R = (int32_t)d[66 * 64];
+}
+
+// ---- second pass of the checkpointed form: only the CONE of the walk is recomputed ---------------------------------------------
+// A walk that enters a chunk at cell (i1, r1) moves down by at most one target position per anti-diagonal, so inside the chunk it
+// stays within t in [i1 - (r1 - r), i1] on row r; and a cell (r, t) depends on (r-1, t-1) and (r-1, t) only, so those cells depend
+// on nothing outside that same cone.  With at most GD_CK_ROWS = 960 rows the cone spans <= 62 blocks: the second pass recomputes
+// the 64 blocks [b0, b0 + 63], b0 = (i1 >> 4) - 63, ONE per lane and without a ring (half the instructions of the two-blocks-per-
+// lane row), restored from the snapshot of the chunk.  Cells of those blocks below the cone come out wrong (their t-1 inputs are
+// not computed) and are never read: wrongness spreads upwards by one cell per row, exactly as fast as the cone's lower edge.
+__device__ __forceinline__ void gdw_cone_restore(WaveLane &L, const WaveK &K, const u32 *ck_chunk /* snapshot of the chunk, lane 0 */, int blk, int r0,
+                                                 const uint8_t *query, int qlen, const uint8_t *target, int tlen)
+{
+	bool have = false;
+	if (blk >= 0) { // ring position blk mod 128 of the first pass: lane (p >> 1), sub-block (p & 1)
+		const int pos = blk & 127;
+		gdw_lane_load(L, ck_chunk + (pos >> 1) + (pos & 1) * 67 * 64);
+		have = L.blk == blk; // (else that position held another block at the time: this one had retired, or had not entered the ring)
+	}
+	if (!have) gdw_fresh_block(L, K, blk, r0 > 0 ? r0 - 1 : 0, query, qlen, target, tlen); // (query bytes of row r0 - 1: the row loop shifts first)
+}
+
+// one anti-diagonal of the cone: lane l holds block b0 + l throughout; pr: this row of the chunk buffer (64 blocks of 16 bytes)
+__device__ __forceinline__ void gdw_cone_row(WaveLane &L, const WaveK &K, bool any_tn, int r, int qlen, int tlen, int w, const uint8_t *query, int b0, int lane,
+                                             int &prev_st_, int &prev_st0, int &prev_up, uint8_t *pr)
+{
+	WaveRow W;
+	W.r = r;
+	gdw_band_uniform(r, qlen, tlen, w, W.st0, W.en0);
+	W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+	W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+	const int advanced = W.st_ > prev_st_;
+	W.use_array = advanced;
+	W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
+	W.set_tr = (W.en0 | 15) >= r;
+	W.ukey = gdw_edge_key(K, r);
+	const u32 pX = gdw_ror1<64>(L.X[7]), pV = gdw_ror1<64>(L.V[7]), pX2 = gdw_ror1<64>(L.X2[7]), pQ = gdw_ror1<64>(L.Qc[3]);
+	// the query streams through the lanes as in the ring; lane 0 takes the byte its cell 0 faces from memory (what block b0 - 1 would hand up)
+	if (r > 0) gdw_shift_query(L, pQ, lane == 0, gdw_seam_byte(query, qlen, r - (b0 << 4)));
+	if (W.set_tr) gdw_reset_tr(L, K, W);
+	if (W.st0 != prev_st0 || W.up != prev_up || advanced) gdw_make_sel(L, W.st0, W.up);
+	gdw_update_scores(L, K, any_tn);
+	if (L.blk >= W.st_ && L.blk <= W.en_) {
+		u32 out[4];
+		gdw_compute<true>(L, K, W, pX, pV, pX2, out);
+		*reinterpret_cast<uint4 *>(pr + (lane << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+	}
+	prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up;
 }
 
 __global__ __launch_bounds__(128) void ksw_extd2_wave128c_kernel(const KswTask *__restrict__ tasks,
@@ -487,9 +534,11 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128c_kernel(const KswTask *
 	// ---- pass 1: state and score, a snapshot at the start of every chunk ----
 	Wave128State S;
 	gdw128_init(S, K, lane, query, qlen, target, tlen);
+	int ck_row = 0, ck_idx = 0;
 	for (int r = 0; r <= rend; ++r) {
-		if ((r & (GD_CK_ROWS - 1)) == 0) {
-			u32 *d = ck + (size_t)(r / GD_CK_ROWS) * GD_CK_REGS * 64 + lane;
+		if (r == ck_row) { // (GD_CK_ROWS is not a power of two: a counter instead of a division per row)
+			u32 *d = ck + (size_t)ck_idx * GD_CK_REGS * 64 + lane;
+			ck_row += GD_CK_ROWS, ++ck_idx;
 			gdw_lane_save(S.L0, d), gdw_lane_save(S.L1, d + 67 * 64);
 			d[134 * 64] = (u32)S.Rf;
 		}
@@ -499,27 +548,29 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128c_kernel(const KswTask *
 		score_out[tid] = S.Rf >> 3;
 		status[tid] = GD_ST_TRACED;
 	}
-	// ---- pass 2: from the last chunk down, recompute a chunk's rows and let the walk consume them ----
+	// ---- pass 2: from the last chunk down, recompute the cone of the walk inside the chunk and let the walk consume it ----
 	GdWalk Wk;
 	gd_walk_init(Wk, qlen, tlen);
+	WaveLane L;
 	for (int kk = n_ck - 1; kk >= 0 && Wk.i >= 0 && Wk.j >= 0; --kk) {
 		const int k = __builtin_amdgcn_readfirstlane(kk);
-		const int r0 = k * GD_CK_ROWS, r1 = r0 + GD_CK_ROWS - 1 < rend ? r0 + GD_CK_ROWS - 1 : rend;
+		const int i1 = __builtin_amdgcn_readfirstlane(Wk.i), rtop = i1 + __builtin_amdgcn_readfirstlane(Wk.j); // where the walk stands
+		const int r0 = k * GD_CK_ROWS;
+		if (rtop < r0) continue; // (cannot happen: a step moves at most two anti-diagonals down; kept for safety)
+		const int r1 = rtop < r0 + GD_CK_ROWS - 1 ? rtop : r0 + GD_CK_ROWS - 1; // rows above the walk are not needed
+		const int b0 = (i1 >> 4) - 63;
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // the snapshot stores of pass 1 / the previous walk's reads of `chunk`
-		const u32 *d = ck + (size_t)k * GD_CK_REGS * 64 + lane;
-		gdw_lane_load(S.L0, d), gdw_lane_load(S.L1, d + 67 * 64);
-		S.Rf = (int)d[134 * 64];
-		S.any_tn = __builtin_amdgcn_ballot_w64((S.L0.tn | S.L1.tn) != 0) != 0;
-		if (r0 == 0) S.prev_st_ = 0, S.prev_st0 = -1, S.prev_up = -1, S.prev_en0 = -1, S.have_f = 0;
-		else { // the loop-carried band quantities of anti-diagonal r0 - 1
+		gdw_cone_restore(L, K, ck + (size_t)k * GD_CK_REGS * 64, b0 + lane, r0, query, qlen, target, tlen);
+		const bool any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0;
+		int prev_st_ = 0, prev_st0 = -1, prev_up = -1;
+		if (r0 > 0) { // the loop-carried band quantities of anti-diagonal r0 - 1
 			int st0, en0;
 			gdw_band_uniform(r0 - 1, qlen, tlen, w, st0, en0);
-			S.prev_st_ = st0 >> 4, S.prev_st0 = st0, S.prev_en0 = en0, S.prev_up = st0 + (((en0 - st0 + 16) >> 4) << 4);
-			S.have_f = en0 == tlen - 1; // en0 never decreases: the corner column was reached before r0 iff it is reached at r0 - 1
+			prev_st_ = st0 >> 4, prev_st0 = st0, prev_up = st0 + (((en0 - st0 + 16) >> 4) << 4);
 		}
-		for (int r = r0; r <= r1; ++r) gdw128_row<true>(S, K, r, qlen, tlen, w, query, target, chunk + (size_t)(r - r0) * row_bytes, mlast, sl);
+		for (int r = r0; r <= r1; ++r) gdw_cone_row(L, K, any_tn, r, qlen, tlen, w, query, b0, lane, prev_st_, prev_st0, prev_up, chunk + (size_t)(r - r0) * 1024);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // this wavefront's own stores: complete, and not served from a stale L1 line
-		gd_walk_rows(Wk, *Tp, chunk, r0, qlen, tlen, w, cigar, lane);
+		gd_walk_rows(Wk, *Tp, chunk, r0, qlen, tlen, w, cigar, lane, 1024, b0);
 	}
 	gd_walk_finish(Wk, *Tp, tid, n_cigar, cigar, lane);
 }

@@ -183,6 +183,29 @@ GDW_HD void gdw_load_block(WaveLane &L, const WaveK &K, int m, int r, const uint
 	L.R = 0;
 }
 
+// the same for any block index (also below block 0 or beyond the target: the cone pass holds 64 consecutive blocks whatever they
+// are); the query bytes are those facing the cells on anti-diagonal rq
+GDW_HD void gdw_fresh_block(WaveLane &L, const WaveK &K, int blk, int rq, const uint8_t *query, int qlen, const uint8_t *target, int tlen)
+{
+	const int tb = blk * 16;
+	L.blk = blk;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) L.U[k] = K.uv0, L.V[k] = K.uv0, L.X[k] = K.cx, L.Y[k] = K.cy, L.X2[k] = K.cx2, L.Y2[k] = K.cy2;
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		u32 tw = 0, qw = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int t = tb + 4 * g + b;
+			tw |= (t >= 0 && t < tlen ? (u32)target[t] : 0u) << (8 * b);
+			qw |= gdw_qbyte(query, qlen, rq - t) << (8 * b);
+		}
+		L.Tb[g] = tw, L.Qc[g] = qw, L.Sb[g] = K.s0, L.SEL[g] = 0x03020100u;
+	}
+	L.tn = (L.Tb[0] | L.Tb[1] | L.Tb[2] | L.Tb[3]) & 0x04040404u;
+	L.R = 0;
+}
+
 // uniform description of one anti-diagonal
 struct WaveRow {
 	int r, st0, en0, st_, en_, up;

@@ -143,6 +143,154 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 	return res;
 }
 
+// ---- the checkpointed wide-band form (ksw_extd2_wave128c_kernel): pass 1 = the 128-position ring without a backtrace, a snapshot
+// of all positions every CK rows; pass 2 = per chunk, from the last one down, the CONE of the walk recomputed by 64 lanes holding the
+// blocks [b0, b0 + 63] (gdw_cone_restore / gdw_cone_row on the device) and consumed by a resumable walk.  A cell the walk reads
+// that the cone pass did not compute is an error.
+static EmuResult emulate_ckpt(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int w, const KswConst &C, int CK)
+{
+	const int LANES = 128;
+	WaveK K;
+	if (!gdw_make_consts(C, K)) { fprintf(stderr, "consts rejected\n"); exit(2); }
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+	std::vector<WaveLane> L(LANES);
+	std::vector<std::vector<WaveLane>> snap;
+	for (int l = 0; l < LANES; ++l) gdw_load_block(L[l], K, l, 0, query, qlen, target, tlen);
+	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
+	for (int r = 0; r <= rend; ++r) { // pass 1 (the row loop of emulate(), nothing stored)
+		if (r % CK == 0) snap.push_back(L);
+		WaveRow W;
+		W.r = r;
+		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+		const int advanced = W.st_ > prev_st_;
+		W.use_array = advanced, W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open, W.set_tr = (W.en0 | 15) >= r, W.ukey = gdw_edge_key(K, r);
+		std::vector<u32> pX(LANES), pV(LANES), pX2(LANES), pQ(LANES);
+		for (int l = 0; l < LANES; ++l) {
+			const int p = (l + LANES - 1) % LANES;
+			pX[l] = L[p].X[7], pV[l] = L[p].V[7], pX2[l] = L[p].X2[7], pQ[l] = L[p].Qc[3];
+		}
+		int reloaded = 0;
+		for (int l = 0; l < LANES; ++l) {
+			if (r > 0) gdw_shift_query(L[l], pQ[l], L[l].blk == prev_st_, gdw_qbyte(query, qlen, r - (prev_st_ << 4)));
+			if (L[l].blk < W.st_) gdw_load_block(L[l], K, L[l].blk + LANES, r, query, qlen, target, tlen), reloaded = 1;
+		}
+		const int remask = W.st0 != prev_st0 || W.up != prev_up || reloaded;
+		bool any_tn = false;
+		for (int l = 0; l < LANES; ++l) any_tn |= L[l].tn != 0;
+		for (int l = 0; l < LANES; ++l) {
+			if (W.set_tr) gdw_reset_tr(L[l], K, W);
+			if (remask) gdw_make_sel(L[l], W.st0, W.up);
+			gdw_update_scores(L[l], K, any_tn);
+		}
+		for (int l = 0; l < LANES; ++l)
+			if (L[l].blk <= W.en_) {
+				u32 out[4];
+				gdw_compute<true>(L[l], K, W, pX[l], pV[l], pX2[l], out);
+			}
+		if (r == 0) L[0].R = gdw_lo(L[0].V[0]) - K.B1 - K.qe8;
+		else for (int l = 0; l < LANES; ++l) L[l].R += gdw_lo(L[l].V[0]) - K.B1;
+		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 15) == 0) {
+			const int m = W.en0 >> 4;
+			const int h = gdw_track_handoff(L[(m - 1) % LANES]);
+			L[m % LANES].R = h + gdw_lo(L[m % LANES].U[0]);
+		}
+		if (W.en0 == tlen - 1) {
+			WaveLane &F = L[mlast % LANES];
+			if (!have_f) Rf = gdw_track_to_slot(F, sl), have_f = 1;
+			else Rf += gdw_cell(F.V, sl) - K.B1;
+		}
+		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
+	}
+	EmuResult res;
+	res.score = Rf / 8;
+	// pass 2
+	int wi = tlen - 1, wj = qlen - 1, state = 0;
+	std::vector<uint32_t> cg; // reversed
+	auto push = [&](uint32_t op, uint32_t len) {
+		if (!cg.empty() && (cg.back() & 0xf) == op) cg.back() += len << 4;
+		else cg.push_back(len << 4 | op);
+	};
+	for (int k = (int)snap.size() - 1; k >= 0 && wi >= 0 && wj >= 0; --k) {
+		const int r0 = k * CK, rtop = wi + wj;
+		if (rtop < r0) continue;
+		const int r1 = rtop < r0 + CK - 1 ? rtop : r0 + CK - 1, b0 = (wi >> 4) - 63;
+		std::vector<WaveLane> Cn(64);
+		for (int l = 0; l < 64; ++l) {
+			const int blk = b0 + l;
+			bool have = false;
+			if (blk >= 0) Cn[l] = snap[k][blk & 127], have = Cn[l].blk == blk;
+			if (!have) gdw_fresh_block(Cn[l], K, blk, r0 > 0 ? r0 - 1 : 0, query, qlen, target, tlen);
+		}
+		bool any_tn = false;
+		for (int l = 0; l < 64; ++l) any_tn |= Cn[l].tn != 0;
+		int pst_ = 0, pst0 = -1, pup = -1;
+		if (r0 > 0) {
+			int st0, en0;
+			gd_band(r0 - 1, qlen, tlen, w, st0, en0);
+			pst_ = st0 >> 4, pst0 = st0, pup = st0 + (((en0 - st0 + 16) >> 4) << 4);
+		}
+		std::vector<uint8_t> buf((size_t)(r1 - r0 + 1) * 1024, 0xEE);
+		std::vector<uint8_t> valid((size_t)(r1 - r0 + 1) * 64, 0);
+		for (int r = r0; r <= r1; ++r) { // gdw_cone_row, statement by statement
+			WaveRow W;
+			W.r = r;
+			gd_band(r, qlen, tlen, w, W.st0, W.en0);
+			W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+			W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+			const int advanced = W.st_ > pst_;
+			W.use_array = advanced, W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open, W.set_tr = (W.en0 | 15) >= r, W.ukey = gdw_edge_key(K, r);
+			u32 pX[64], pV[64], pX2[64], pQ[64];
+			for (int l = 0; l < 64; ++l) {
+				const int p = (l + 63) % 64;
+				pX[l] = Cn[p].X[7], pV[l] = Cn[p].V[7], pX2[l] = Cn[p].X2[7], pQ[l] = Cn[p].Qc[3];
+			}
+			for (int l = 0; l < 64; ++l) {
+				if (r > 0) gdw_shift_query(Cn[l], pQ[l], l == 0, gdw_qbyte(query, qlen, r - b0 * 16));
+				if (W.set_tr) gdw_reset_tr(Cn[l], K, W);
+				if (W.st0 != pst0 || W.up != pup || advanced) gdw_make_sel(Cn[l], W.st0, W.up);
+				gdw_update_scores(Cn[l], K, any_tn);
+			}
+			for (int l = 0; l < 64; ++l)
+				if (Cn[l].blk >= W.st_ && Cn[l].blk <= W.en_) {
+					u32 out[4];
+					gdw_compute<true>(Cn[l], K, W, pX[l], pV[l], pX2[l], out);
+					memcpy(&buf[(size_t)(r - r0) * 1024 + l * 16], out, 16);
+					valid[(size_t)(r - r0) * 64 + l] = 1;
+				}
+			pst_ = W.st_, pst0 = W.st0, pup = W.up;
+		}
+		while (wi >= 0 && wj >= 0 && wi + wj >= r0) { // the walk (SR/ksw2.h:131-163) over the rows of this chunk
+			const int r = wi + wj;
+			int st0, en0, force_state = -1;
+			gd_band(r, qlen, tlen, w, st0, en0);
+			const int off = st0 & ~15, off_end = en0 | 15;
+			if (wi < off) force_state = 2;
+			if (wi > off_end) force_state = 1;
+			uint32_t tmp = 0;
+			if (force_state < 0) {
+				const int b = (wi >> 4) - b0, c = wi & 15, g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
+				if (r > r1 || b < 0 || b > 63 || !valid[(size_t)(r - r0) * 64 + b]) { fprintf(stderr, "walk left the cone: r=%d i=%d chunk [%d,%d] b0=%d\n", r, wi, r0, r1, b0); exit(2); }
+				const uint8_t bb = buf[(size_t)(r - r0) * 1024 + b * 16 + 4 * g + h], nb = (uint8_t)~bb;
+				tmp = (uint8_t)((4 - (bb & 7)) | ((nb >> 4) & 0x08) | ((nb >> 2) & 0x10) | (nb & 0x20) | ((nb << 2) & 0x40));
+			}
+			if (state == 0) state = tmp & 7;
+			else if (!(tmp >> (state + 2) & 1)) state = 0;
+			if (state == 0) state = tmp & 7;
+			if (force_state >= 0) state = force_state;
+			if (state == 0) push(0, 1), --wi, --wj;
+			else if (state == 1 || state == 3) push(2, 1), --wi;
+			else push(1, 1), --wj;
+		}
+	}
+	if (wi >= 0) push(2, wi + 1);
+	if (wj >= 0) push(1, wj + 1);
+	res.cigar.assign(cg.rbegin(), cg.rend());
+	return res;
+}
+
 static void mutate(std::mt19937 &g, const std::vector<uint8_t> &t, std::vector<uint8_t> &q, double sub, double ins, double del, double nfrac)
 {
 	std::uniform_real_distribution<double> U(0, 1);
@@ -163,6 +311,7 @@ int main(int argc, char **argv)
 	const unsigned seed = argc > 1 ? atoi(argv[1]) : 1;
 	const int n = argc > 2 ? atoi(argv[2]) : 200, LANES = argc > 3 ? atoi(argv[3]) : 64;
 	g_single = argc > 4 && !strcmp(argv[4], "single");
+	const int ckpt = argc > 5 && !strcmp(argv[4], "ckpt") ? atoi(argv[5]) : 0; // ./wave_emul <seed> <n> 128 ckpt <rows per chunk>
 	std::mt19937 g(seed);
 	const int presets[3][6] = {{2, 8, 12, 2, 24, 1}, {1, 4, 6, 2, 26, 1}, {2, 4, 4, 2, 24, 1}};
 	int n_run = 0, n_bad = 0, n_skip = 0;
@@ -210,7 +359,7 @@ int main(int argc, char **argv)
 		// (the extz2 oracle has the SSE score rule only: identical to the AVX-512 table except for query byte 7, which the single runs avoid)
 		if (g_single) gdo_ksw_extz2(qlen, q.data(), tlen, t.data(), 5, mat, P[2], P[3], w, -1, 0, GDO_EZ_APPROX_MAX, &ez);
 		else gdo_ksw_extd2(qlen, q.data(), tlen, t.data(), 5, mat, P[2], P[3], P[4], P[5], w, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez);
-		EmuResult e = emulate(LANES, q.data(), qlen, t.data(), tlen, w, C);
+		EmuResult e = ckpt ? emulate_ckpt(q.data(), qlen, t.data(), tlen, w, C, ckpt) : emulate(LANES, q.data(), qlen, t.data(), tlen, w, C);
 		++n_run;
 		bool ok = e.score == ez.score && (int)e.cigar.size() == ez.n_cigar && (ez.n_cigar == 0 || !memcmp(e.cigar.data(), ez.cigar, 4 * ez.n_cigar));
 		if (!ok) {

@@ -29,3 +29,13 @@ def test_single_affine_form_matches_extz2_oracle(emul, lanes):
     out = subprocess.run([emul, "9", "300", str(lanes), "single"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
+
+
+@pytest.mark.parametrize("seed,n,rows", [(4, 60, 960), (7, 40, 320), (8, 30, 64)])
+def test_checkpointed_cone_pass_matches_oracle(emul, seed, n, rows):
+    """the wide-band kernel without a stored backtrace: pass 1 on the 128-position ring with snapshots every `rows` anti-diagonals,
+    pass 2 recomputing only the cone of the walk with one block per lane (gdw_cone_row); a cell the walk reads outside the
+    recomputed cone is an error"""
+    out = subprocess.run([emul, str(seed), str(n), "128", "ckpt", str(rows)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout
