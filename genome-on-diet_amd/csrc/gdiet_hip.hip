@@ -22,6 +22,7 @@
 #include "ksw_backtrack.hip.h"
 #include "ksw_wave.hip.h"
 #include "ksw_extz2_exact.hip.h"
+#include "ksw_exts2.hip.h"
 
 struct DevBuf {
 	void *p = nullptr;
@@ -823,6 +824,80 @@ extern "C" int gdiet_hip_ksw_extz2_batch_ex(gdiet_ctx *ctx, int n, const uint8_t
 	                   (const int32_t *)ctx->status.p, d_score, (int32_t *)ctx->ncig.p, (uint32_t *)ctx->cigar.p, 0, (const int32_t *)nullptr, (const int32_t *)d_start);
 	GD_HIP(hipEventRecord(ctx->ev[2], s));
 	GD_HIP(hipMemcpyAsync(ez, d_ez, sizeof(GdExtzOut) * n, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipMemcpyAsync(n_cigar, ctx->ncig.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipMemcpyAsync(cigar, ctx->cigar.p, sizeof(uint32_t) * cb, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipStreamSynchronize(s));
+	GD_HIP(hipGetLastError());
+	for (int i = 0; i < n; ++i)
+		if (n_cigar[i] > cigar_off[i + 1] - cigar_off[i]) { ctx->err = "CIGAR of alignment " + std::to_string(i) + " needs " + std::to_string(n_cigar[i]) + " ops"; return GDIET_E_CIGAR_CAP; }
+	return GDIET_OK;
+}
+
+// ksw_exts2 (splice-aware extension; not called by GDiet): ksw_exts2.hip.h
+extern "C" int gdiet_hip_ksw_exts2_batch(gdiet_ctx *ctx, int n, const uint8_t *qseq, const int64_t *qoff, const uint8_t *tseq, const int64_t *toff,
+                                         const uint8_t *junc, const int8_t *mat, int8_t q, int8_t e, int8_t q2, int8_t noncan, int32_t zdrop,
+                                         int8_t junc_bonus, int32_t flag, gdiet_ksw_extz_t *ez, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	if (n <= 0) return GDIET_OK;
+	if (!qseq || !qoff || !tseq || !toff || !mat || !ez || !n_cigar || !cigar || !cigar_off) { ctx->err = "NULL argument"; return GDIET_E_PARAM; }
+	const int32_t known = GD_EZ_SCORE_ONLY | GD_EZ_RIGHT | GD_EZ_GENERIC_SC | GD_EZ_APPROX_MAX | GD_EZ_APPROX_DROP | GD_EZ_EXTZ_ONLY | GD_EZ_REV_CIGAR |
+	                      GD_EZ_SPLICE_FOR | GD_EZ_SPLICE_REV | GD_EZ_SPLICE_FLANK;
+	if (flag & ~known) { ctx->err = "gdiet_hip_ksw_exts2_batch: unknown flag bit"; return GDIET_E_PARAM; }
+	if (q2 <= q + e || e <= 0) { ctx->err = "ksw_exts2 needs q2 > q + e (and e > 0): the reference returns without aligning"; return GDIET_E_PARAM; } // :72
+	(void)hipSetDevice(ctx->device);
+	hipStream_t s = ctx->stream;
+	KswsConst K;
+	K.q = q, K.e = e, K.q2 = q2, K.noncan = noncan, K.zdrop = zdrop, K.junc_bonus = junc_bonus, K.flag = flag;
+	K.sc_mch = mat[0], K.sc_mis = mat[1], K.sc_N = mat[24] == 0 ? -e : mat[24];
+	memcpy(K.mat, mat, 25);
+	{ // :86-90
+		int min_sc = mat[1];
+		for (int t = 1; t < 25; ++t) min_sc = std::min<int>(min_sc, mat[t]);
+		if (-min_sc > 2 * (q + e)) { ctx->err = "-min_sc > 2*(q+e): the reference returns without aligning"; return GDIET_E_PARAM; }
+	}
+	K.long_thres = (q2 - q) / e - 1; // :92-95
+	if (q2 > q + e + K.long_thres * e) ++K.long_thres;
+	K.long_diff = K.long_thres * e - (q2 - q);
+	int rc;
+	if ((rc = gd_host_grow(ctx, ctx->h_tasks, sizeof(KswTask) * (size_t)n))) return rc;
+	KswTask *h_tasks = (KswTask *)ctx->h_tasks.p;
+	size_t bt = 0;
+	int max_cap = 0;
+	for (int i = 0; i < n; ++i) {
+		KswTask &T = h_tasks[i];
+		T.qoff = qoff[i], T.toff = toff[i], T.qlen = (int)(qoff[i + 1] - qoff[i]), T.tlen = (int)(toff[i + 1] - toff[i]), T.w = -1;
+		if (T.qlen <= 0 || T.tlen <= 0) { ctx->err = "empty sequence in batch (the reference returns without aligning)"; return GDIET_E_PARAM; }
+		T.cig_off = cigar_off[i], T.cig_cap = (int32_t)std::min<int64_t>(cigar_off[i + 1] - cigar_off[i], 0x7fffffff);
+		T.exact_score = GD_NEG_INF, T.kind = GD_KIND_GENERIC, T.pad = 0;
+		T.row_bytes = (((T.qlen < T.tlen ? T.qlen : T.tlen) + 15) / 16 + 1) * 16; // n_col_ * 16, :80
+		T.bt_off = (int64_t)bt;
+		if (!(flag & GD_EZ_SCORE_ONLY)) bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
+		max_cap = std::max(max_cap, gd_generic_cap(T.qlen, T.tlen, -1));
+	}
+	const size_t lds = (size_t)max_cap * 10 + 16;
+	if (lds > 160 * 1024 - 1024) { ctx->err = "alignment longer than the LDS window of the ksw_exts2 kernel (min(qlen, tlen) <= ~8000)"; return GDIET_E_PARAM; }
+	const size_t qb = (size_t)qoff[n], tb = (size_t)toff[n], cb = (size_t)cigar_off[n];
+	if ((rc = gd_grow(ctx, ctx->arena, bt + 256))) return rc;
+	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->qseq, qb + 64))) return rc;
+	if ((rc = gd_grow(ctx, ctx->tseq, 2 * tb + 128))) return rc; // target | junction annotation
+	if ((rc = gd_grow(ctx, ctx->score, sizeof(GdExtzOut) * (size_t)n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->ncig, sizeof(int32_t) * n))) return rc;
+	if ((rc = gd_grow(ctx, ctx->cigar, sizeof(uint32_t) * (cb + 1)))) return rc;
+	uint8_t *d_junc = junc ? (uint8_t *)ctx->tseq.p + tb + 64 : nullptr;
+	GD_HIP(hipMemcpyAsync(ctx->qseq.p, qseq, qb, hipMemcpyHostToDevice, s));
+	GD_HIP(hipMemcpyAsync(ctx->tseq.p, tseq, tb, hipMemcpyHostToDevice, s));
+	if (junc) GD_HIP(hipMemcpyAsync(d_junc, junc, tb, hipMemcpyHostToDevice, s));
+	GD_HIP(hipMemcpyAsync(ctx->tasks.p, h_tasks, sizeof(KswTask) * n, hipMemcpyHostToDevice, s));
+	if (lds > 64 * 1024) GD_HIP(hipFuncSetAttribute((const void *)ksw_exts2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	ctx->last_mask = 2, ctx->last_was_async = false, ctx->last_split = 0;
+	GD_HIP(hipEventRecord(ctx->ev[0], s));
+	hipLaunchKernelGGL(ksw_exts2_kernel, dim3(n), dim3(64), lds, s, (const KswTask *)ctx->tasks.p, n, (const uint8_t *)ctx->qseq.p, (const uint8_t *)ctx->tseq.p,
+	                   (const uint8_t *)d_junc, (uint8_t *)ctx->arena.p, (GdExtzOut *)ctx->score.p, (int32_t *)ctx->ncig.p, (uint32_t *)ctx->cigar.p, K, max_cap);
+	GD_HIP(hipEventRecord(ctx->ev[1], s));
+	GD_HIP(hipEventRecord(ctx->ev[2], s));
+	GD_HIP(hipMemcpyAsync(ez, ctx->score.p, sizeof(GdExtzOut) * n, hipMemcpyDeviceToHost, s));
 	GD_HIP(hipMemcpyAsync(n_cigar, ctx->ncig.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
 	GD_HIP(hipMemcpyAsync(cigar, ctx->cigar.p, sizeof(uint32_t) * cb, hipMemcpyDeviceToHost, s));
 	GD_HIP(hipStreamSynchronize(s));

@@ -69,6 +69,8 @@ def load_library():
     lib.gdiet_hip_ksw_extd2_batch_dev.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(KswScore),
                                                   vp, vp, vp, vp, i64p, i64p, i32p, vp]
     lib.gdiet_hip_ksw_extz2_batch.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, C.POINTER(KswScore), i32p, i32p, u32p, i64p]
+    lib.gdiet_hip_ksw_exts2_batch.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, u8p, C.POINTER(C.c_int8), C.c_int8, C.c_int8, C.c_int8, C.c_int8, C.c_int32,
+                                              C.c_int8, C.c_int32, i32p, i32p, u32p, i64p]
     lib.gdiet_hip_ksw_extz2_batch_ex.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, C.POINTER(KswScore), C.c_int32, C.c_int32, i32p, i32p, u32p, i64p]
     _lib = lib
     return lib
@@ -194,6 +196,26 @@ class Context:
         rc = self.lib.gdiet_hip_ksw_extz2_batch_ex(self._h, n, _ptr(qbuf, C.c_uint8), _ptr(qoff, C.c_int64), _ptr(tbuf, C.c_uint8),
                                                    _ptr(toff, C.c_int64), _ptr(w, C.c_int32), C.byref(score), int(zdrop), int(end_bonus),
                                                    _ptr(ez, C.c_int32), _ptr(nc, C.c_int32), _ptr(cg, C.c_uint32), _ptr(coff, C.c_int64))
+        self._check(rc)
+        return [dict(zip(self.EXTZ_FIELDS, (int(v) for v in ez[i]))) for i in range(n)], [cg[coff[i]:coff[i] + nc[i]].copy() for i in range(n)]
+
+    def ksw_exts2_batch(self, queries, targets, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, juncs=None):
+        """ksw_exts2_sse (splice-aware extension, reference ksw2.h:71) for a batch; mat = int8[25]; juncs: None or one
+        uint8 array per target; returns (list of dicts with the scalars of ksw_extz_t, list of uint32 CIGAR arrays)"""
+        n = len(queries)
+        qbuf, qoff = pack(queries)
+        tbuf, toff = pack(targets)
+        jbuf = None
+        if juncs is not None:
+            jbuf, _ = pack([np.ascontiguousarray(j, np.uint8) for j in juncs])
+        mat = np.ascontiguousarray(mat, np.int8)
+        coff = np.zeros(n + 1, np.int64)
+        coff[1:] = np.cumsum([len(q_) + len(t_) + 2 for q_, t_ in zip(queries, targets)])
+        ez, nc, cg = np.zeros((n, 10), np.int32), np.zeros(n, np.int32), np.zeros(int(coff[-1]) + 1, np.uint32)
+        rc = self.lib.gdiet_hip_ksw_exts2_batch(self._h, n, _ptr(qbuf, C.c_uint8), _ptr(qoff, C.c_int64), _ptr(tbuf, C.c_uint8), _ptr(toff, C.c_int64),
+                                                None if jbuf is None else _ptr(jbuf, C.c_uint8), _ptr(mat, C.c_int8), int(q), int(e), int(q2), int(noncan),
+                                                int(zdrop), int(junc_bonus), int(flag), _ptr(ez, C.c_int32), _ptr(nc, C.c_int32), _ptr(cg, C.c_uint32),
+                                                _ptr(coff, C.c_int64))
         self._check(rc)
         return [dict(zip(self.EXTZ_FIELDS, (int(v) for v in ez[i]))) for i in range(n)], [cg[coff[i]:coff[i] + nc[i]].copy() for i in range(n)]
 

@@ -124,6 +124,22 @@ int gdiet_hip_ksw_extz2_batch_ex(gdiet_ctx *ctx, int n,
                                  const int32_t *w, const gdiet_ksw_score_t *sc, int32_t zdrop, int32_t end_bonus,
                                  gdiet_ksw_extz_t *ez, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off);
 
+/* ---- SURVEY 8f rank 4 (kernel half): batched splice-aware extension alignment -------------------------------------------
+ * Replaces ksw_exts2_sse + ksw_backtrack (SR/ksw2_exts2_sse.c:34-416, SR/ksw2.h:71-72,131-163).  GDiet keeps this kernel of
+ * minimap2 in its tree (SR/align.c:363 is its only call site, under MM_F_SPLICE) but no GDiet preset reaches it; it is provided
+ * for a minimap2-compatible splice mode.  Arguments as the reference's: mat = the 5 x 5 matrix (m = 5), q / e the short gap,
+ * q2 the long-gap (intron) open cost (must exceed q + e), noncan the penalty of a non-canonical splice site, junc = one
+ * annotation byte per target base laid out like tseq (NULL: none) with junc_bonus, flag = any of KSW_EZ_SCORE_ONLY 0x01,
+ * RIGHT 0x02, GENERIC_SC 0x04, APPROX_MAX 0x08, APPROX_DROP 0x10, EXTZ_ONLY 0x40, REV_CIGAR 0x80, SPLICE_FOR 0x100,
+ * SPLICE_REV 0x200, SPLICE_FLANK 0x400 (SR/ksw2.h:9-18).  No band (the reference has none).  ez[i]: every scalar of ksw_extz_t;
+ * CIGAR in BAM ops incl. N (3) for long gaps of at least long_thres bases.  One wavefront per alignment, state in LDS:
+ * min(qlen, tlen) is limited to ~8000. */
+int gdiet_hip_ksw_exts2_batch(gdiet_ctx *ctx, int n,
+                              const uint8_t *qseq, const int64_t *qoff,
+                              const uint8_t *tseq, const int64_t *toff, const uint8_t *junc,
+                              const int8_t *mat, int8_t q, int8_t e, int8_t q2, int8_t noncan, int32_t zdrop, int8_t junc_bonus, int32_t flag,
+                              gdiet_ksw_extz_t *ez, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off);
+
 /* make sure the context owns at least `bytes` of device workspace (backtrace arena); returns GDIET_E_NOMEM
  * if the device cannot provide it.  gdiet_hip_ksw_extd2_batch() grows the arena by itself. */
 int gdiet_hip_reserve(gdiet_ctx *ctx, size_t bytes);

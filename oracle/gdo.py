@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 NEG_INF = -0x40000000
 EZ_AVX512_SC = 0x10000
 EZ_SCORE_ONLY, EZ_RIGHT, EZ_GENERIC_SC, EZ_APPROX_MAX, EZ_APPROX_DROP, EZ_EXTZ_ONLY, EZ_REV_CIGAR = 1, 2, 4, 8, 0x10, 0x40, 0x80
+EZ_SPLICE_FOR, EZ_SPLICE_REV, EZ_SPLICE_FLANK = 0x100, 0x200, 0x400
 
 
 class GdoExtz(C.Structure):
@@ -47,6 +48,8 @@ def load_oracle():
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GdoExtz)]
     lib.gdo_exact_match.argtypes = [C.c_int, u8p, C.c_int, u8p]
     lib.gdo_exact_match.restype = C.c_int
+    lib.gdo_ksw_exts2.argtypes = [C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                                  C.c_int, C.c_int8, C.c_int, u8p, C.POINTER(GdoExtz)]
     return lib
 
 
@@ -64,6 +67,8 @@ def load_ref(variant="lr_avx"):
         lib.ksw_extd2_avx512.argtypes = d2
     lib.ksw_extz2_sse.argtypes = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RefExtz)]
+    lib.ksw_exts2_sse.argtypes = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                                  C.c_int, C.c_int8, C.c_int, u8p, C.POINTER(RefExtz)]
     lib.exact_match_sse.argtypes = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RefExtz), C.POINTER(C.c_bool),
                                     C.POINTER(C.c_int)]
@@ -110,6 +115,27 @@ def oracle_extz2(lib, query, target, mat, q, e, w, zdrop=-1, end_bonus=0, flag=E
     lib.gdo_ksw_extz2(len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8), m, _p(mat, C.c_int8),
                       q, e, w, zdrop, end_bonus, flag, C.byref(ez))
     return _result(ez, ez.zdropped, ez.max)
+
+
+def oracle_exts2(lib, query, target, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, junc=None, m=5):
+    """ksw_exts2 (splice-aware extension), oracle form"""
+    ez = GdoExtz()
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    jp = _p(np.ascontiguousarray(junc, np.uint8), C.c_uint8) if junc is not None else None
+    lib.gdo_ksw_exts2(len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8), m, _p(mat, C.c_int8),
+                      q, e, q2, noncan, zdrop, junc_bonus, flag, jp, C.byref(ez))
+    return _result(ez, ez.zdropped, ez.max)
+
+
+def ref_exts2(lib, query, target, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, junc=None, m=5):
+    ez = RefExtz()
+    query = np.ascontiguousarray(query, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    jp = _p(np.ascontiguousarray(junc, np.uint8), C.c_uint8) if junc is not None else None
+    lib.ksw_exts2_sse(None, len(query), _p(query, C.c_uint8), len(target), _p(target, C.c_uint8), m, _p(mat, C.c_int8),
+                      q, e, q2, noncan, zdrop, junc_bonus, flag, jp, C.byref(ez))
+    return _result(ez, ez.max_zd >> 31, ez.max_zd & 0x7fffffff)
 
 
 def oracle_exact_match(lib, query, target):

@@ -463,3 +463,210 @@ void gdo_ksw_extz2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 		free(p), free(off);
 	}
 }
+
+/* ---- ksw_exts2 (splice-aware extension; SURVEY 8f rank 4: not called by GDiet) ---------------------------------------------
+ * restates SR/ksw2_exts2_sse.c:34-416 in its SSE4.1 form (the form ksw2_dispatch.c:94-106 picks on any CPU with SSE4.1; the SSE2
+ * emulation differs only in its score-only x2 update, :236-239, marked "TODO: check if this is correct" there).  Flat memory layout
+ * as the reference's (:91-95), so that 16-byte stores past the end of s[] land where they land there. */
+void gdo_ksw_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc,
+                   gdo_extz_t *ez)
+{
+	int r, t, i, qe = q + e, n_col_, *off = 0, *off_end = 0, tlen_, qlen_, last_st, last_en, max_sc, min_sc, long_thres, long_diff;
+	int with_cigar = !(flag & GDO_EZ_SCORE_ONLY), approx_max = !!(flag & GDO_EZ_APPROX_MAX);
+	int32_t *H = 0, H0 = 0, last_H0_t = 0;
+	u8t *mem, *qr, *sf, *p = 0;
+	i8 *u, *v, *x, *y, *x2, *donor, *acceptor;
+	u8t *s;
+	i8 sc_mch, sc_mis, sc_N;
+
+	reset_extz(ez);
+	if (m <= 1 || qlen <= 0 || tlen <= 0 || q2 <= q + e) return; /* :72 */
+	sc_mch = mat[0], sc_mis = mat[1];
+	sc_N = mat[m * m - 1] == 0 ? (i8)-e : mat[m * m - 1];
+	tlen_ = (tlen + 15) / 16;
+	n_col_ = ((qlen < tlen ? qlen : tlen) + 15) / 16 + 1;
+	qlen_ = (qlen + 15) / 16;
+	for (t = 1, max_sc = mat[0], min_sc = mat[1]; t < m * m; ++t) {
+		max_sc = max_sc > mat[t] ? max_sc : mat[t];
+		min_sc = min_sc < mat[t] ? min_sc : mat[t];
+	}
+	if (-min_sc > 2 * (q + e)) return; /* :90 */
+	long_thres = (q2 - q) / e - 1;
+	if (q2 > q + e + long_thres * e) ++long_thres;
+	long_diff = long_thres * e - (q2 - q);
+
+	mem = (u8t *)calloc((size_t)tlen_ * 9 + qlen_ + 1, 16); /* u|v|x|y|x2|donor|acceptor|s|sf|qr|slack, :97-101 */
+	u = (i8 *)mem, v = u + tlen_ * 16, x = v + tlen_ * 16, y = x + tlen_ * 16, x2 = y + tlen_ * 16;
+	donor = x2 + tlen_ * 16, acceptor = donor + tlen_ * 16;
+	s = (u8t *)(acceptor + tlen_ * 16), sf = s + tlen_ * 16, qr = sf + tlen_ * 16;
+	memset(u, -q - e, (size_t)tlen_ * 16 * 4);
+	memset(x2, -q2, (size_t)tlen_ * 16);
+	if (!approx_max) {
+		H = (int32_t *)malloc((size_t)tlen_ * 16 * 4);
+		for (t = 0; t < tlen_ * 16; ++t) H[t] = GDO_NEG_INF;
+	}
+	if (with_cigar) {
+		p = (u8t *)malloc(((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16);
+		off = (int *)malloc((size_t)(qlen + tlen - 1) * sizeof(int) * 2);
+		off_end = off + qlen + tlen - 1;
+	}
+	for (t = 0; t < qlen; ++t) qr[t] = query[qlen - 1 - t];
+	memcpy(sf, target, tlen);
+
+	if (flag & (GDO_EZ_SPLICE_FOR | GDO_EZ_SPLICE_REV)) { /* donor / acceptor signals, :119-171 (0/1/2/3 encoding assumed there too) */
+		int semi_cost = flag & GDO_EZ_SPLICE_FLANK ? -noncan / 2 : 0;
+		const int fw = !(flag & GDO_EZ_REV_CIGAR);
+		memset(donor, -noncan, (size_t)tlen_ * 16);
+		memset(acceptor, -noncan, (size_t)tlen_ * 16);
+		for (t = 0; t < tlen - 4; ++t) {
+			int can_type = 0;
+			if (fw) {
+				if ((flag & GDO_EZ_SPLICE_FOR) && target[t + 1] == 2 && target[t + 2] == 3) can_type = 1; /* GTr... */
+				if ((flag & GDO_EZ_SPLICE_REV) && target[t + 1] == 1 && target[t + 2] == 3) can_type = 1; /* CTr... */
+				if (can_type && (target[t + 3] == 0 || target[t + 3] == 2)) can_type = 2;
+			} else {
+				if ((flag & GDO_EZ_SPLICE_FOR) && target[t + 1] == 2 && target[t + 2] == 0) can_type = 1; /* GAy... */
+				if ((flag & GDO_EZ_SPLICE_REV) && target[t + 1] == 1 && target[t + 2] == 0) can_type = 1; /* CAy... */
+				if (can_type && (target[t + 3] == 1 || target[t + 3] == 3)) can_type = 2;
+			}
+			if (can_type) donor[t] = can_type == 2 ? 0 : (i8)semi_cost;
+		}
+		if (junc)
+			for (t = 0; t < tlen - 1; ++t)
+				if (fw ? (((flag & GDO_EZ_SPLICE_FOR) && (junc[t + 1] & 1)) || ((flag & GDO_EZ_SPLICE_REV) && (junc[t + 1] & 8)))
+				       : (((flag & GDO_EZ_SPLICE_FOR) && (junc[t + 1] & 2)) || ((flag & GDO_EZ_SPLICE_REV) && (junc[t + 1] & 4))))
+					donor[t] = add8(donor[t], junc_bonus);
+		for (t = 2; t < tlen; ++t) {
+			int can_type = 0;
+			if (fw) {
+				if ((flag & GDO_EZ_SPLICE_FOR) && target[t - 1] == 0 && target[t] == 2) can_type = 1; /* ...yAG */
+				if ((flag & GDO_EZ_SPLICE_REV) && target[t - 1] == 0 && target[t] == 1) can_type = 1; /* ...yAC */
+				if (can_type && (target[t - 2] == 1 || target[t - 2] == 3)) can_type = 2;
+			} else {
+				if ((flag & GDO_EZ_SPLICE_FOR) && target[t - 1] == 3 && target[t] == 2) can_type = 1; /* ...rTG */
+				if ((flag & GDO_EZ_SPLICE_REV) && target[t - 1] == 3 && target[t] == 1) can_type = 1; /* ...rTC */
+				if (can_type && (target[t - 2] == 0 || target[t - 2] == 2)) can_type = 2;
+			}
+			if (can_type) acceptor[t] = can_type == 2 ? 0 : (i8)semi_cost;
+		}
+		if (junc)
+			for (t = 0; t < tlen; ++t)
+				if (fw ? (((flag & GDO_EZ_SPLICE_FOR) && (junc[t] & 2)) || ((flag & GDO_EZ_SPLICE_REV) && (junc[t] & 4)))
+				       : (((flag & GDO_EZ_SPLICE_FOR) && (junc[t] & 1)) || ((flag & GDO_EZ_SPLICE_REV) && (junc[t] & 8))))
+					acceptor[t] = add8(acceptor[t], junc_bonus);
+	}
+
+	for (r = 0, last_st = last_en = -1; r < qlen + tlen - 1; ++r) {
+		int st = 0, en = tlen - 1, st0, en0, st_, en_;
+		i8 x1, x21, v1;
+		u8t *qrr = qr + (qlen - 1 - r);
+		if (st < r - qlen + 1) st = r - qlen + 1;
+		if (en > r) en = r;
+		st0 = st, en0 = en;
+		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
+		if (st > 0) { /* :183-191 */
+			if (st - 1 >= last_st && st - 1 <= last_en) x1 = x[st - 1], x21 = x2[st - 1], v1 = v[st - 1];
+			else x1 = (i8)(-q - e), x21 = (i8)-q2, v1 = (i8)(-q - e);
+		} else {
+			x1 = (i8)(-q - e), x21 = (i8)-q2;
+			v1 = r == 0 ? (i8)(-q - e) : r < long_thres ? (i8)-e : r == long_thres ? (i8)long_diff : 0;
+		}
+		if (en >= r) {
+			y[r] = (i8)(-q - e);
+			u[r] = r == 0 ? (i8)(-q - e) : r < long_thres ? (i8)-e : r == long_thres ? (i8)long_diff : 0;
+		}
+		fill_scores(flag & GDO_EZ_GENERIC_SC, st0, en0, s, sf, qrr, m, mat, sc_mch, sc_mis, sc_N); /* :197-217 */
+		st_ = st / 16, en_ = en / 16;
+		if (with_cigar) off[r] = st, off_end[r] = en;
+		for (t = st_; t <= en_; ++t) {
+			i8 ox[16], ov[16], ox2[16];
+			u8t *pr = with_cigar ? p + ((size_t)r * n_col_ - st_ + t) * 16 : 0;
+			memcpy(ox, x + t * 16, 16), memcpy(ov, v + t * 16, 16), memcpy(ox2, x2 + t * 16, 16);
+			for (i = 0; i < 16; ++i) {
+				const int c = t * 16 + i;
+				i8 z = (i8)s[c], xt1 = i ? ox[i - 1] : x1, vt1 = i ? ov[i - 1] : v1, x2t1 = i ? ox2[i - 1] : x21, ut = u[c];
+				i8 a = add8(xt1, vt1), b = add8(y[c], ut), a2 = add8(x2t1, vt1), a2a = add8(a2, acceptor[c]), tmp, dn = donor[c];
+				u8t d;
+				if (!(flag & GDO_EZ_RIGHT) || !with_cigar) { /* :258-264 (and the score-only form :228-230: same z) */
+					d = a > z ? 1 : 0;
+					z = max8(z, a);
+					d = b > z ? 2 : d;
+					z = max8(z, b);
+					d = a2a > z ? 3 : d;
+					z = max8(z, a2a);
+				} else { /* :303-309 */
+					d = z > a ? 0 : 1;
+					z = max8(z, a);
+					d = z > b ? d : 2;
+					z = max8(z, b);
+					d = z > a2a ? d : 3;
+					z = max8(z, a2a);
+				}
+				u[c] = sub8(z, vt1), v[c] = sub8(z, ut); /* block2 :61-66 */
+				tmp = sub8(z, q);
+				a = sub8(a, tmp), b = sub8(b, tmp), a2 = sub8(a2, sub8(z, q2));
+				if (!(flag & GDO_EZ_RIGHT) || !with_cigar) {
+					x[c] = sub8(a > 0 ? a : 0, (i8)qe), d |= a > 0 ? 0x08 : 0;
+					y[c] = sub8(b > 0 ? b : 0, (i8)qe), d |= b > 0 ? 0x10 : 0;
+					x2[c] = sub8(max8(a2, dn), q2), d |= a2 > dn ? 0x20 : 0;
+				} else {
+					x[c] = sub8(0 > a ? 0 : a, (i8)qe), d |= 0 > a ? 0 : 0x08;
+					y[c] = sub8(0 > b ? 0 : b, (i8)qe), d |= 0 > b ? 0 : 0x10;
+					x2[c] = sub8(max8(dn, a2), q2), d |= dn > a2 ? 0 : 0x20;
+				}
+				if (pr) pr[i] = d;
+			}
+			x1 = ox[15], v1 = ov[15], x21 = ox2[15];
+		}
+		if (!approx_max) { /* :339-383 */
+			int32_t max_H, max_t;
+			if (r > 0) {
+				int32_t HH[4], tt[4], en1 = st0 + (en0 - st0) / 4 * 4;
+				max_H = H[en0] = en0 > 0 ? H[en0 - 1] + u[en0] : H[en0] + v[en0];
+				max_t = en0;
+				for (i = 0; i < 4; ++i) HH[i] = max_H, tt[i] = max_t;
+				for (t = st0; t < en1; t += 4)
+					for (i = 0; i < 4; ++i) {
+						H[t + i] += (int32_t)v[t + i];
+						if (H[t + i] > HH[i]) HH[i] = H[t + i], tt[i] = t;
+					}
+				for (i = 0; i < 4; ++i)
+					if (max_H < HH[i]) max_H = HH[i], max_t = tt[i] + i;
+				for (; t < en0; ++t) {
+					H[t] += (int32_t)v[t];
+					if (H[t] > max_H) max_H = H[t], max_t = t;
+				}
+			} else H[0] = v[0] - qe, max_H = H[0], max_t = 0;
+			if (en0 == tlen - 1 && H[en0] > ez->mte) ez->mte = H[en0], ez->mte_q = r - en;
+			if (r - st0 == qlen - 1 && H[st0] > ez->mqe) ez->mqe = H[st0], ez->mqe_t = st0;
+			if (apply_zdrop(ez, max_H, r, max_t, zdrop, 0)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez->score = H[tlen - 1];
+		} else { /* :384-402 */
+			if (r > 0) {
+				if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+					int32_t d0 = v[last_H0_t], d1 = u[last_H0_t + 1];
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (last_H0_t >= st0 && last_H0_t <= en0) {
+					H0 += v[last_H0_t];
+				} else {
+					++last_H0_t, H0 += u[last_H0_t];
+				}
+			} else H0 = v[0] - qe, last_H0_t = 0;
+			if ((flag & GDO_EZ_APPROX_DROP) && apply_zdrop(ez, H0, r, last_H0_t, zdrop, 0)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez->score = H0;
+		}
+		last_st = st, last_en = en;
+	}
+	free(mem);
+	if (!approx_max) free(H);
+	if (with_cigar) { /* :407-413 */
+		int rev_cigar = !!(flag & GDO_EZ_REV_CIGAR);
+		if (!ez->zdropped && !(flag & GDO_EZ_EXTZ_ONLY))
+			gdo_backtrack(rev_cigar, long_thres, p, off, off_end, n_col_ * 16, tlen - 1, qlen - 1, &ez->m_cigar, &ez->n_cigar, &ez->cigar);
+		else if (ez->max_t >= 0 && ez->max_q >= 0)
+			gdo_backtrack(rev_cigar, long_thres, p, off, off_end, n_col_ * 16, ez->max_t, ez->max_q, &ez->m_cigar, &ez->n_cigar, &ez->cigar);
+		free(p), free(off);
+	}
+}

@@ -9,6 +9,8 @@
  *   gdo_ksw_extz2   <- SR/ksw2_extz2_sse.c:31-312   (single affine gap; BASELINE config 2)
  *   gdo_backtrack   <- SR/ksw2.h:131-163 (+ ksw_push_cigar :115-125)
  *   gdo_exact_match <- SR/exact_match_sse.c:23-91
+ *   gdo_ksw_exts2   <- SR/ksw2_exts2_sse.c:34-416   (splice-aware extension; SURVEY 8f rank 4, dead code in GDiet)
+ *   gdo_lchain_dp   <- SR/lchain.c:9-190            (mg_lchain_dp + mg_chain_backtrack + compact_a; oracle/gdo_lchain.c; same rank)
  *
  * Pinning: oracle/pin_ksw2.py checks these against the reference itself (oracle/_ref/libgdiet_*.so built by
  * oracle/Makefile.ref: ksw_extd2_sse, ksw_extd2_avx512, ksw_extz2_sse, exact_match_sse) on seeded fuzz, and
@@ -34,6 +36,9 @@ extern "C" {
 #define GDO_EZ_APPROX_DROP 0x10
 #define GDO_EZ_EXTZ_ONLY   0x40
 #define GDO_EZ_REV_CIGAR   0x80
+#define GDO_EZ_SPLICE_FOR  0x100
+#define GDO_EZ_SPLICE_REV  0x200
+#define GDO_EZ_SPLICE_FLANK 0x400
 /* ours: score cells the way ksw_extd2_avx512 does (see fill_scores); only differs from the SSE rule for bytes outside 0..4 */
 #define GDO_EZ_AVX512_SC   0x10000
 
@@ -56,6 +61,11 @@ void gdo_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 
 void gdo_ksw_extz2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                    int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, gdo_extz_t *ez);
+
+/* SURVEY 8f rank 4 (not called by GDiet): the splice-aware extension kernel, SR/ksw2_exts2_sse.c:34-416; junc may be NULL */
+void gdo_ksw_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc,
+                   gdo_extz_t *ez);
 
 /* returns 1 if query[0..qlen) == target[0..qlen) under the reference's 16-byte-chunk rule, else 0 */
 int gdo_exact_match(int qlen, const uint8_t *query, int tlen, const uint8_t *target);

@@ -25,3 +25,19 @@ def load_ksw(name):
 def load_exact():
     z = np.load(os.path.join(GOLDEN, "exact_match.npz"))
     return [(z["q"][z["qo"][i]:z["qo"][i + 1]], z["t"][z["to"][i]:z["to"][i + 1]], int(z["expect"][i])) for i in range(len(z["expect"]))]
+
+
+def load_exts2():
+    """tests/golden/ksw2_exts2.npz (oracle/pin_rank4.py): inputs and ksw_exts2_sse's own outputs"""
+    z = np.load(os.path.join(GOLDEN, "ksw2_exts2.npz"))
+    out = []
+    for i in range(len(z["params"])):
+        q = z["q"][z["qo"][i]:z["qo"][i + 1]]
+        t = z["t"][z["to"][i]:z["to"][i + 1]]
+        go, ge, go2, noncan, zdrop, junc_bonus, flag, has_junc = [int(v) for v in z["params"][i]]
+        junc = z["junc"][z["to"][i]:z["to"][i + 1]] if has_junc else None
+        cig = z["cigar_bytes"][z["cigar_off"][i]:z["cigar_off"][i + 1]].view(np.uint32)
+        sc = dict(zip(SCALARS, [int(v) for v in z["scalars"][i]]))
+        out.append(dict(q=q, t=t, mat=z["mat"][i], go=go, ge=ge, go2=go2, noncan=noncan, zdrop=zdrop, junc_bonus=junc_bonus, flag=flag, junc=junc,
+                        cigar=cig, **sc))
+    return out
