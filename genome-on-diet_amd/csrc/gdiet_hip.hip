@@ -909,6 +909,58 @@ extern "C" int gdiet_hip_ksw_exts2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 
 #include "map_pipeline.hip.h"
 
+// ---- SURVEY 8f rank 4, chaining half: mg_lchain_dp for a batch of reads (lchain.hip.h on the device, lchain_host.h on host threads) ----
+#include "lchain.hip.h"
+#include "lchain_host.h"
+extern "C" int gdiet_hip_lchain_dp_batch(gdiet_ctx *ctx, int n_reads, const uint64_t *a, const int64_t *aoff, int32_t max_dist_x, int32_t max_dist_y,
+                                         int32_t bw, int32_t max_skip, int32_t max_iter, int32_t min_cnt, int32_t min_sc, float chn_pen_gap,
+                                         float chn_pen_skip, int32_t is_cdna, int32_t n_seg, int32_t *n_u, int64_t *n_v, uint64_t *u, uint64_t *a_out)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	if (n_reads <= 0) return GDIET_OK;
+	if (!a || !aoff || !n_u || !n_v || !u || !a_out) { ctx->err = "NULL argument"; return GDIET_E_PARAM; }
+	const int64_t tot = aoff[n_reads];
+	for (int i = 0; i < n_reads; ++i) {
+		if (aoff[i + 1] < aoff[i] || aoff[i + 1] - aoff[i] > 0x7fffffff) { ctx->err = "anchor offsets must ascend (at most 2^31 - 1 anchors per read)"; return GDIET_E_PARAM; }
+		n_u[i] = 0, n_v[i] = 0;
+	}
+	if (tot == 0) return GDIET_OK;
+	(void)hipSetDevice(ctx->device);
+	hipStream_t s = ctx->stream;
+	GdChainOpt O;
+	O.max_dist_x = max_dist_x < bw ? bw : max_dist_x; // SR/lchain.c:136-137
+	O.max_dist_y = (max_dist_y < bw && !is_cdna) ? bw : max_dist_y;
+	O.bw = bw, O.max_skip = max_skip, O.max_iter = max_iter, O.min_cnt = min_cnt, O.min_sc = min_sc;
+	O.chn_pen_gap = chn_pen_gap, O.chn_pen_skip = chn_pen_skip, O.is_cdna = is_cdna, O.n_seg = n_seg;
+	int rc;
+	// device: anchors | offsets | f | p | v | t   (qseq / tseq / score / status buffers of the context reused as plain workspace)
+	if ((rc = gd_grow(ctx, ctx->qseq, sizeof(uint64_t) * 2 * (size_t)tot + 64))) return rc;
+	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(int64_t) * ((size_t)n_reads + 1) + 64))) return rc;
+	if ((rc = gd_grow(ctx, ctx->score, sizeof(int32_t) * 4 * (size_t)tot + 64))) return rc;
+	if ((rc = gd_host_grow(ctx, ctx->h_res, sizeof(int32_t) * 3 * (size_t)tot + 64))) return rc;
+	int32_t *d_f = (int32_t *)ctx->score.p, *d_p = d_f + tot, *d_v = d_p + tot, *d_t = d_v + tot;
+	int32_t *h_f = (int32_t *)ctx->h_res.p, *h_p = h_f + tot, *h_v = h_p + tot;
+	GD_HIP(hipMemcpyAsync(ctx->qseq.p, a, sizeof(uint64_t) * 2 * (size_t)tot, hipMemcpyHostToDevice, s));
+	GD_HIP(hipMemcpyAsync(ctx->tasks.p, aoff, sizeof(int64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, s));
+	ctx->last_mask = 0, ctx->last_was_async = false, ctx->last_split = 0;
+	GD_HIP(hipEventRecord(ctx->ev[0], s));
+	hipLaunchKernelGGL(lchain_fill_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, (const uint64_t *)ctx->qseq.p, (const int64_t *)ctx->tasks.p, O, d_f, d_p, d_v, d_t);
+	GD_HIP(hipEventRecord(ctx->ev[1], s));
+	GD_HIP(hipEventRecord(ctx->ev[2], s));
+	GD_HIP(hipMemcpyAsync(h_f, d_f, sizeof(int32_t) * 3 * (size_t)tot, hipMemcpyDeviceToHost, s));
+	GD_HIP(hipStreamSynchronize(s));
+	GD_HIP(hipGetLastError());
+	gd_parallel_for(ctx, ctx->lane_threads, n_reads, [&](int i) {
+		static thread_local std::vector<GdlPair> z, b;
+		static thread_local std::vector<int32_t> t;
+		static thread_local std::vector<uint64_t> u2;
+		const int64_t o = aoff[i], n = aoff[i + 1] - o;
+		if (n <= 0) return;
+		n_u[i] = gdl_chains_of_read(n, (const GdlPair *)a + o, h_f + o, h_p + o, h_v + o, min_cnt, min_sc, u + o, (GdlPair *)a_out + o, &n_v[i], z, t, b, u2);
+	});
+	return GDIET_OK;
+}
+
 // ---- read input (input half) ---------------------------------------------------------------------------
 #include "fastx_reader.h"
 struct gdiet_fastx { GdFastx *r; };

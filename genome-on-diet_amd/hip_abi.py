@@ -69,6 +69,8 @@ def load_library():
     lib.gdiet_hip_ksw_extd2_batch_dev.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(KswScore),
                                                   vp, vp, vp, vp, i64p, i64p, i32p, vp]
     lib.gdiet_hip_ksw_extz2_batch.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, C.POINTER(KswScore), i32p, i32p, u32p, i64p]
+    lib.gdiet_hip_lchain_dp_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), i64p] + [C.c_int32] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                              i32p, i64p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.gdiet_hip_ksw_exts2_batch.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, u8p, C.POINTER(C.c_int8), C.c_int8, C.c_int8, C.c_int8, C.c_int8, C.c_int32,
                                               C.c_int8, C.c_int32, i32p, i32p, u32p, i64p]
     lib.gdiet_hip_ksw_extz2_batch_ex.argtypes = [vp, C.c_int, u8p, i64p, u8p, i64p, i32p, C.POINTER(KswScore), C.c_int32, C.c_int32, i32p, i32p, u32p, i64p]
@@ -198,6 +200,23 @@ class Context:
                                                    _ptr(ez, C.c_int32), _ptr(nc, C.c_int32), _ptr(cg, C.c_uint32), _ptr(coff, C.c_int64))
         self._check(rc)
         return [dict(zip(self.EXTZ_FIELDS, (int(v) for v in ez[i]))) for i in range(n)], [cg[coff[i]:coff[i] + nc[i]].copy() for i in range(n)]
+
+    def lchain_dp_batch(self, anchors, par):
+        """SURVEY 8f rank 4: mg_lchain_dp (reference mmpriv.h:102) for a batch; anchors: list of uint64[n_i, 2] arrays (x, y) sorted by x;
+        par: dict with the reference's scalar arguments.  Returns a list of (u uint64[n_u], a uint64[n_v, 2]) per read."""
+        n = len(anchors)
+        aoff = np.zeros(n + 1, np.int64)
+        aoff[1:] = np.cumsum([len(x) for x in anchors])
+        tot = int(aoff[-1])
+        a = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint64).reshape(-1, 2) for x in anchors]) if tot else np.zeros((0, 2), np.uint64))
+        n_u, n_v = np.zeros(n, np.int32), np.zeros(n, np.int64)
+        u, a_out = np.zeros(max(tot, 1), np.uint64), np.zeros((max(tot, 1), 2), np.uint64)
+        rc = self.lib.gdiet_hip_lchain_dp_batch(self._h, n, _ptr(a.reshape(-1) if tot else np.zeros(2, np.uint64), C.c_uint64), _ptr(aoff, C.c_int64),
+                                                *[int(par[k]) for k in ("max_dist_x", "max_dist_y", "bw", "max_skip", "max_iter", "min_cnt", "min_sc")],
+                                                float(par["chn_pen_gap"]), float(par["chn_pen_skip"]), int(par["is_cdna"]), int(par["n_seg"]),
+                                                _ptr(n_u, C.c_int32), _ptr(n_v, C.c_int64), _ptr(u, C.c_uint64), _ptr(a_out.reshape(-1), C.c_uint64))
+        self._check(rc)
+        return [(u[aoff[i]:aoff[i] + n_u[i]].copy(), a_out[aoff[i]:aoff[i] + n_v[i]].copy()) for i in range(n)]
 
     def ksw_exts2_batch(self, queries, targets, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, juncs=None):
         """ksw_exts2_sse (splice-aware extension, reference ksw2.h:71) for a batch; mat = int8[25]; juncs: None or one

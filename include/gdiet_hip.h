@@ -140,6 +140,20 @@ int gdiet_hip_ksw_exts2_batch(gdiet_ctx *ctx, int n,
                               const int8_t *mat, int8_t q, int8_t e, int8_t q2, int8_t noncan, int32_t zdrop, int8_t junc_bonus, int32_t flag,
                               gdiet_ksw_extz_t *ez, int32_t *n_cigar, uint32_t *cigar, const int64_t *cigar_off);
 
+/* ---- SURVEY 8f rank 4 (chaining half): batched anchor chaining ------------------------------------------------------------
+ * Replaces mg_lchain_dp (SR/lchain.c:124-190, SR/mmpriv.h:102-104) for a batch of reads; like ksw_exts2 it is code of minimap2
+ * that GDiet keeps and never calls (GDiet votes instead of chaining), provided for a minimap2-compatible mode.  a = the
+ * anchors of all reads as (x, y) pairs of uint64 (x: tid<<33 | rev<<32 | tpos, y: flags<<40 | q_span<<32 | q_pos; per read
+ * sorted by x as minimap2 sorts them), read i = pairs aoff[i] .. aoff[i+1]; the scalar parameters are the reference's.
+ * Outputs, per read at the read's own offset (a chain set never has more chains or anchors than the read has anchors):
+ * n_u[i] chains, u[aoff[i] + k] = score<<32 | n_anchors of chain k, a_out (pairs, at 2 * aoff[i]) = the chains' anchors, n_v[i]
+ * of them -- the very arrays mg_lchain_dp returns (same chain order, same anchor order).  The reference frees its input; here
+ * `a` stays untouched.  The O(n * max_iter) fill runs on the GPU, one wavefront per read; the chains are cut on host threads. */
+int gdiet_hip_lchain_dp_batch(gdiet_ctx *ctx, int n_reads, const uint64_t *a, const int64_t *aoff,
+                              int32_t max_dist_x, int32_t max_dist_y, int32_t bw, int32_t max_skip, int32_t max_iter, int32_t min_cnt, int32_t min_sc,
+                              float chn_pen_gap, float chn_pen_skip, int32_t is_cdna, int32_t n_seg,
+                              int32_t *n_u, int64_t *n_v, uint64_t *u, uint64_t *a_out);
+
 /* make sure the context owns at least `bytes` of device workspace (backtrace arena); returns GDIET_E_NOMEM
  * if the device cannot provide it.  gdiet_hip_ksw_extd2_batch() grows the arena by itself. */
 int gdiet_hip_reserve(gdiet_ctx *ctx, size_t bytes);

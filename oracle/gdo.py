@@ -48,6 +48,11 @@ def load_oracle():
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GdoExtz)]
     lib.gdo_exact_match.argtypes = [C.c_int, u8p, C.c_int, u8p]
     lib.gdo_exact_match.restype = C.c_int
+    u64p = C.POINTER(C.c_uint64)
+    lib.gdo_lchain_dp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int64, u64p,
+                                  C.POINTER(C.c_int), C.POINTER(u64p), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.gdo_lchain_dp.restype = u64p
+    lib.gdo_radix_sort_128x.argtypes = [u64p, C.c_int64]
     lib.gdo_ksw_exts2.argtypes = [C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
                                   C.c_int, C.c_int8, C.c_int, u8p, C.POINTER(GdoExtz)]
     return lib
@@ -69,6 +74,11 @@ def load_ref(variant="lr_avx"):
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RefExtz)]
     lib.ksw_exts2_sse.argtypes = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
                                   C.c_int, C.c_int8, C.c_int, u8p, C.POINTER(RefExtz)]
+    if hasattr(lib, "mg_lchain_dp"):
+        u64p = C.POINTER(C.c_uint64)
+        lib.mg_lchain_dp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                     C.POINTER(C.c_int), C.POINTER(u64p), C.c_void_p]
+        lib.mg_lchain_dp.restype = u64p
     lib.exact_match_sse.argtypes = [C.c_void_p, C.c_int, u8p, C.c_int, u8p, C.c_int8, i8p, C.c_int8, C.c_int8,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RefExtz), C.POINTER(C.c_bool),
                                     C.POINTER(C.c_int)]
@@ -219,3 +229,108 @@ def make_pair(rng, tlen, sub=0.01, ins=0.003, dele=0.003, n_frac=0.0, big_indel=
     if len(query) == 0:
         query = np.zeros(1, np.uint8)
     return np.ascontiguousarray(query), np.ascontiguousarray(target)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SURVEY 8f rank 4, chaining half: mg_lchain_dp (SR/lchain.c:124) -- oracle, reference and seeded inputs
+# ---------------------------------------------------------------------------------------------------------------
+LCHAIN_FIELDS = ("max_dist_x", "max_dist_y", "bw", "max_skip", "max_iter", "min_cnt", "min_sc", "chn_pen_gap", "chn_pen_skip", "is_cdna", "n_seg")
+_libc.malloc.argtypes = [C.c_size_t]
+_libc.malloc.restype = C.c_void_p
+
+
+def _lchain_out(b, n_u, u):
+    nu = n_u.value
+    if not b or nu == 0:
+        if b:
+            _libc.free(C.cast(b, C.c_void_p))
+        return dict(u=np.zeros(0, np.uint64), a=np.zeros((0, 2), np.uint64))
+    uu = np.ctypeslib.as_array(u, shape=(nu,)).copy()
+    n_v = int((uu & 0xffffffff).sum())
+    aa = np.ctypeslib.as_array(b, shape=(2 * n_v,)).copy().reshape(n_v, 2)
+    _libc.free(C.cast(b, C.c_void_p)), _libc.free(C.cast(u, C.c_void_p))
+    return dict(u=uu, a=aa)
+
+
+def oracle_lchain(lib, a, par, want_fp=False):
+    """a: uint64[n, 2] anchors (x, y) sorted by x; par: dict with LCHAIN_FIELDS"""
+    a = np.ascontiguousarray(a, np.uint64)
+    n = len(a)
+    n_u, u = C.c_int(0), C.POINTER(C.c_uint64)()
+    f, p = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int64)
+    b = lib.gdo_lchain_dp(*[par[k] for k in LCHAIN_FIELDS], n, _p(a.reshape(-1), C.c_uint64), C.byref(n_u), C.byref(u), _p(f, C.c_int32), _p(p, C.c_int64))
+    out = _lchain_out(b, n_u, u)
+    if want_fp:
+        out["f"], out["p"] = f[:n], p[:n]
+    return out
+
+
+def ref_lchain(lib, a, par):
+    """the reference's own mg_lchain_dp: its input array is kfree'd inside (km = NULL: libc), so it gets a malloc'd copy"""
+    a = np.ascontiguousarray(a, np.uint64)
+    n = len(a)
+    buf = _libc.malloc(max(16 * n, 16))
+    C.memmove(buf, a.ctypes.data, 16 * n)
+    n_u, u = C.c_int(0), C.POINTER(C.c_uint64)()
+    b = lib.mg_lchain_dp(*[par[k] for k in LCHAIN_FIELDS], n, buf if n else None, C.byref(n_u), C.byref(u), None)
+    if n == 0:
+        _libc.free(buf)
+    return _lchain_out(b, n_u, u)
+
+
+def same_lchain(o, r):
+    return len(o["u"]) == len(r["u"]) and bool(np.all(o["u"] == r["u"])) and o["a"].shape == r["a"].shape and bool(np.all(o["a"] == r["a"]))
+
+
+def lchain_cases(rng, n_cases):
+    """yield (anchors uint64[n, 2] sorted by x, parameter dict): a few colinear runs per target / strand with indel drift, repeats
+    (anchors sharing query or target positions), noise anchors, sometimes two query segments (paired-end style) or cDNA-like jumps"""
+    for ci in range(n_cases):
+        k = int(rng.choice([11, 15, 19]))
+        n_seg = 2 if ci % 9 == 4 else 1
+        is_cdna = int(ci % 7 == 3)
+        xs, ys = [], []
+        for rid in range(int(rng.integers(1, 4))):
+            for strand in (0, 1):
+                for _ in range(int(rng.integers(0, 4))):
+                    m = int(rng.integers(2, 400 if ci % 10 else 1500))
+                    tpos, qpos = int(rng.integers(100, 200000)), int(rng.integers(0, 3000))
+                    seg = int(rng.integers(0, n_seg))
+                    for _ in range(m):
+                        step = int(rng.integers(1, 60))
+                        tpos += step + (int(rng.integers(-8, 9)) if rng.random() < 0.2 else 0) + (int(rng.integers(200, 4000)) if is_cdna and rng.random() < 0.02 else 0)
+                        qpos += step
+                        if rng.random() < 0.03 and n_seg > 1:
+                            seg ^= 1
+                        xs.append(rid << 33 | strand << 32 | (tpos & 0x7fffffff))
+                        ys.append(seg << 48 | k << 32 | (qpos & 0x7fffffff))
+                        if rng.random() < 0.05:  # a repeat: same query position elsewhere on the target
+                            xs.append(rid << 33 | strand << 32 | ((tpos + int(rng.integers(1, 500))) & 0x7fffffff))
+                            ys.append(seg << 48 | k << 32 | (qpos & 0x7fffffff))
+        for _ in range(int(rng.integers(0, 40))):  # noise
+            xs.append(int(rng.integers(0, 3)) << 33 | int(rng.integers(0, 2)) << 32 | int(rng.integers(0, 200000)))
+            ys.append(int(rng.integers(0, n_seg)) << 48 | k << 32 | int(rng.integers(0, 5000)))
+        a = np.array(list(zip(xs, ys)), np.uint64).reshape(-1, 2)
+        if len(a):
+            a = a[np.argsort(a[:, 0], kind="stable")]
+        par = dict(max_dist_x=int(rng.choice([500, 5000])), max_dist_y=int(rng.choice([500, 5000])), bw=int(rng.choice([100, 500, 2000])),
+                   max_skip=int(rng.choice([5, 25])), max_iter=int(rng.choice([50, 5000])), min_cnt=int(rng.choice([2, 3])),
+                   min_sc=int(rng.choice([20, 40])), chn_pen_gap=float(rng.choice([0.12, 0.8])) * 0.01 * k, chn_pen_skip=float(rng.choice([0.0, 0.5])) * 0.01 * k,
+                   is_cdna=is_cdna, n_seg=n_seg)
+        yield a, par
+
+
+def save_lchain_golden(path, gold):
+    """gold: list of ((anchors, par), reference result)"""
+    def pack(arrs, dt):
+        offs = np.zeros(len(arrs) + 1, np.int64)
+        offs[1:] = np.cumsum([len(x) for x in arrs])
+        return (np.concatenate(arrs).astype(dt) if arrs and offs[-1] else np.zeros(0, dt)), offs
+    ax, ao = pack([g[0][0][:, 0] for g in gold], np.uint64)
+    ay, _ = pack([g[0][0][:, 1] for g in gold], np.uint64)
+    ipar = np.array([[g[0][1][k] for k in LCHAIN_FIELDS if k not in ("chn_pen_gap", "chn_pen_skip")] for g in gold], np.int32)
+    fpar = np.array([[g[0][1]["chn_pen_gap"], g[0][1]["chn_pen_skip"]] for g in gold], np.float32)
+    u, uo = pack([g[1]["u"] for g in gold], np.uint64)
+    bx, bo = pack([g[1]["a"][:, 0] for g in gold], np.uint64)
+    by, _ = pack([g[1]["a"][:, 1] for g in gold], np.uint64)
+    np.savez_compressed(path, ax=ax, ay=ay, ao=ao, ipar=ipar, fpar=fpar, u=u, uo=uo, bx=bx, by=by, bo=bo)

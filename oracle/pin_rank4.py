@@ -113,7 +113,7 @@ def main():
                 bad_lc += 1
                 if bad_lc <= 5:
                     print("MISMATCH lchain oracle vs reference", i, len(case[0]), len(o["u"]), len(r["u"]))
-            if i < 160:
+            if i < 64:
                 gold_lc.append((case, r))
         print("mg_lchain_dp: cases=%d oracle_vs_reference_mismatch=%d (golden: %d cases, %d chains)"
               % (max(200, args.fuzz // 5), bad_lc, len(gold_lc), sum(len(g[1]["u"]) for g in gold_lc)))

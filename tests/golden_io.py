@@ -41,3 +41,20 @@ def load_exts2():
         out.append(dict(q=q, t=t, mat=z["mat"][i], go=go, ge=ge, go2=go2, noncan=noncan, zdrop=zdrop, junc_bonus=junc_bonus, flag=flag, junc=junc,
                         cigar=cig, **sc))
     return out
+
+
+LCHAIN_INT = ("max_dist_x", "max_dist_y", "bw", "max_skip", "max_iter", "min_cnt", "min_sc", "is_cdna", "n_seg")
+
+
+def load_lchain():
+    """tests/golden/lchain_dp.npz (oracle/pin_rank4.py): anchors + parameters and mg_lchain_dp's own outputs (u[], rearranged anchors)"""
+    z = np.load(os.path.join(GOLDEN, "lchain_dp.npz"))
+    out = []
+    for i in range(len(z["ipar"])):
+        a = np.stack([z["ax"][z["ao"][i]:z["ao"][i + 1]], z["ay"][z["ao"][i]:z["ao"][i + 1]]], axis=1).astype(np.uint64)
+        par = dict(zip(LCHAIN_INT, [int(v) for v in z["ipar"][i]]))
+        par["chn_pen_gap"], par["chn_pen_skip"] = float(z["fpar"][i][0]), float(z["fpar"][i][1])
+        u = z["u"][z["uo"][i]:z["uo"][i + 1]]
+        b = np.stack([z["bx"][z["bo"][i]:z["bo"][i + 1]], z["by"][z["bo"][i]:z["bo"][i + 1]]], axis=1).astype(np.uint64)
+        out.append(dict(a=a, par=par, u=u, b=b))
+    return out

@@ -59,3 +59,34 @@ def test_exts2_refuses_what_the_reference_returns_on(gpu_ctx, pkg):
         gpu_ctx.ksw_exts2_batch([q], [q], mat, 4, 2, 6, 5)  # q2 <= q + e (SR/ksw2_exts2_sse.c:72)
     with pytest.raises(pkg.GdietError):
         gpu_ctx.ksw_exts2_batch([q], [q], np.array([1, -40, -40, -40, 0] * 4 + [0] * 5, np.int8), 4, 2, 24, 5)  # -min_sc > 2 (q + e), :90
+
+
+def test_lchain_matches_reference_golden(gpu_ctx):
+    from golden_io import load_lchain
+    cases = load_lchain()
+    groups = {}
+    for c in cases:  # the scalar arguments of mg_lchain_dp are per batch
+        groups.setdefault(tuple(sorted(c["par"].items())), []).append(c)
+    n_chains = 0
+    for cs in groups.values():
+        out = gpu_ctx.lchain_dp_batch([c["a"] for c in cs], cs[0]["par"])
+        for c, (u, b) in zip(cs, out):
+            assert np.array_equal(u, c["u"]) and np.array_equal(b, c["b"]), (len(c["a"]), c["par"])
+            n_chains += len(u)
+    assert n_chains >= 300
+
+
+def test_lchain_fresh_reads_against_oracle(gpu_ctx, oracle):
+    """one batch of 300 reads with common parameters (max_iter small enough to cut windows, max_skip small enough to leave scans early)"""
+    gdo, lib = oracle
+    rng = np.random.default_rng(77)
+    for par_pick in range(3):
+        reads, par = [], None
+        for a, p in gdo.lchain_cases(rng, 300):
+            par = par or dict(p, max_iter=(50, 5000, 300)[par_pick], max_skip=(5, 25, 2)[par_pick], n_seg=2, is_cdna=par_pick == 2)
+            reads.append(a)
+        reads.append(np.zeros((0, 2), np.uint64))  # an empty read
+        out = gpu_ctx.lchain_dp_batch(reads, par)
+        for a, (u, b) in zip(reads, out):
+            o = gdo.oracle_lchain(lib, a, par)
+            assert np.array_equal(u, o["u"]) and np.array_equal(b, o["a"]), (len(a), par)
