@@ -381,7 +381,7 @@ static int gd_host_grow(gdiet_ctx *ctx, DevBuf &b, size_t bytes)
 	free(b.p);
 	b.p = nullptr, b.cap = 0;
 	const size_t want = bytes + (bytes >> 2) + 4096;
-	b.p = malloc(want);
+	if (posix_memalign(&b.p, 256, want)) b.p = nullptr; // (256-byte aligned: the runtime's copy kernels pick their form by the alignment of both ends)
 	if (!b.p) { ctx->err = "out of host memory (" + std::to_string(want) + " bytes)"; return GDIET_E_NOMEM; }
 	b.cap = want;
 	return GDIET_OK;

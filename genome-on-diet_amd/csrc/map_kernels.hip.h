@@ -147,12 +147,19 @@ __device__ __forceinline__ void map_bitonic_locs(GdLoc *a, unsigned P2, unsigned
 		}
 }
 
+// The sort buffer is DYNAMIC shared memory of vote_cap entries (a power of two <= MAP_VOTE_CAP, sized by the host from the largest
+// hit count of the batch: 16 KB for HiFi reads instead of 64).  With a static 64 KB array the compiler, knowing that the LDS allows
+// one wavefront per SIMD, padded the kernel's register count from 46 to 264 (the count that pins that occupancy): a wavefront
+// that cannot start next to the DP kernel's wavefronts of another batch in flight until three of them have left the same SIMD.
+// (Measured in the pipeline: no change of the HiFi step time either way -- the DP kernel leaves little to share -- but the
+// kernel no longer depends on the tail of a DP kernel to run.)
 __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const int64_t *__restrict__ roff, GdIdxView I, MapDevOpt O,
                                                            const MapReadScratch *__restrict__ sc, const GdSeed *__restrict__ seed_arena,
                                                            const MapSeedOut *__restrict__ seeds, const int64_t *__restrict__ hit_off,
-                                                           GdLoc *__restrict__ hits, MapVoteOut *__restrict__ out)
+                                                           GdLoc *__restrict__ hits, MapVoteOut *__restrict__ out, unsigned vote_cap)
 {
-	__shared__ GdLoc s_buf[MAP_VOTE_CAP]; // one strand at a time: 64 KB
+	extern __shared__ __attribute__((aligned(16))) uint8_t vote_lds[];
+	GdLoc *s_buf = reinterpret_cast<GdLoc *>(vote_lds); // one strand at a time
 	const int rid = blockIdx.x;
 	if (rid >= n_reads) return;
 	const unsigned lane = threadIdx.x;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const in
 	}
 	__syncthreads();
 	// S7: one strand at a time through LDS: padded with +inf to a power of two, bitonic sort by target, back to its global array.
-	// A strand with more hits than the LDS buffer holds (long ONT reads: ~9 seeds per 100 bases) is sorted in runs of MAP_VOTE_CAP
+	// A strand with more hits than the LDS buffer holds (long ONT reads: ~9 seeds per 100 bases) is sorted in runs of vote_cap
 	// and the runs are merged pairwise in global memory, every lane merging one slice of the output (merge path); the sequential
 	// sort by one lane this replaces cost tens of milliseconds for such a read.
 	GdLoc inf;
@@ -210,8 +217,8 @@ __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const in
 		GdLoc *g = strand ? a_rev : a_for;
 		const unsigned cnt = strand ? nr : nf;
 		if (cnt < 2) continue;
-		for (unsigned c0 = 0; c0 < cnt; c0 += MAP_VOTE_CAP) {
-			const unsigned m_ = cnt - c0 < MAP_VOTE_CAP ? cnt - c0 : MAP_VOTE_CAP;
+		for (unsigned c0 = 0; c0 < cnt; c0 += vote_cap) {
+			const unsigned m_ = cnt - c0 < vote_cap ? cnt - c0 : vote_cap;
 			unsigned P2 = 64;
 			while (P2 < m_) P2 <<= 1;
 			for (unsigned i = lane; i < P2; i += 64) s_buf[i] = i < m_ ? g[c0 + i] : inf;
@@ -220,9 +227,9 @@ __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const in
 			for (unsigned i = lane; i < m_; i += 64) g[c0 + i] = s_buf[i];
 			__syncthreads();
 		}
-		if (cnt > MAP_VOTE_CAP) {
+		if (cnt > vote_cap) {
 			GdLoc *src = g, *dst = tmp; // tmp holds n_a entries: room for either strand
-			for (unsigned width = MAP_VOTE_CAP; width < cnt; width <<= 1) {
+			for (unsigned width = vote_cap; width < cnt; width <<= 1) {
 				for (unsigned s0 = 0; s0 < cnt; s0 += 2 * width) {
 					const unsigned a_n = cnt - s0 < width ? cnt - s0 : width, b_n = cnt - s0 - a_n < width ? cnt - s0 - a_n : width;
 					const GdLoc *A = src + s0, *B = A + a_n;

@@ -467,10 +467,16 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// ---- S6, S7, V1, V3, G1a -----------------------------------------------------------------------------------------
 	// long reads: one read per wavefront (parallel expansion + LDS sort); short reads (a handful of hits each): one read per thread
 	const int spread = ctx->spread && (B.roff[n] - B.roff[0]) / n >= 1024;
-	if (spread == 1 && ctx->vote_wave)
-		hipLaunchKernelGGL(map_vote_wave_kernel, dim3(n), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p, (const GdSeed *)ctx->m_seed.p,
-		                   (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p, (MapVoteOut *)ctx->m_voteout.p);
-	else
+	if (spread == 1 && ctx->vote_wave) {
+		// LDS sort buffer of the batch: the largest hit count of a read bounds either strand (see the kernel)
+		int64_t max_hits = 0;
+		for (int i = 0; i < n; ++i) max_hits = std::max(max_hits, hoff[i + 1] - hoff[i]);
+		unsigned vote_cap = 256;
+		while (vote_cap < MAP_VOTE_CAP && (int64_t)vote_cap < max_hits) vote_cap <<= 1;
+		hipLaunchKernelGGL(map_vote_wave_kernel, dim3(n), dim3(64), sizeof(GdLoc) * (size_t)vote_cap, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+		                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
+		                   (MapVoteOut *)ctx->m_voteout.p, vote_cap);
+	} else
 		hipLaunchKernelGGL(map_vote_kernel, dim3(spread ? n : (n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 		                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
 		                   (MapVoteOut *)ctx->m_voteout.p, spread);
@@ -553,8 +559,15 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	if (bad_box) { ctx->err = "degenerate DP box (candidate window outside the read/contig); the reference's behaviour is undefined there"; return GDIET_E_PARAM; }
 	ctx->stage_s[2] += gd_now() - t0, t0 = gd_now();
 	mark("g:fill");
-	if ((rc = gd_host_grow(ctx, ctx->h_res, sizeof(int32_t) * 2 * (size_t)std::max(nb, 1)))) return rc;
-	int32_t *h_score = (int32_t *)ctx->h_res.p, *h_ncig = h_score + nb;
+	// scores | CIGAR lengths come back in ONE copy with both ends 256-byte aligned.  (As two copies the second, starting at an address
+	// that is not a multiple of 16, took the runtime's dword copy kernel with 1024-thread workgroups: 16 wavefronts that need four
+	// free slots on every SIMD of one CU, which the DP kernel of the next batch -- five wavefronts per SIMD -- never leaves.  That
+	// 37 KB copy then finished only in the tail of the other batch's DP kernel, 45-60 ms later (kernel trace, round 2): invisible in
+	// the throughput with three batches in flight, but it is the batch's latency.  Pinned host buffers were tried as well and cost 8 %
+	// of the step: the host stages write these tables.)
+	const size_t nbp = ((size_t)std::max(nb, 1) + 63) & ~(size_t)63;
+	if ((rc = gd_host_grow(ctx, ctx->h_res, sizeof(int32_t) * 2 * nbp))) return rc;
+	int32_t *h_score = (int32_t *)ctx->h_res.p, *h_ncig = h_score + nbp;
 	const bool post_dev = ctx->post_on_device != 0;
 	if (post_dev && (rc = gd_host_grow(ctx, ctx->h_post, sizeof(GdPostOut) * (size_t)std::max(nb, 1)))) return rc;
 	const GdPostOut *h_post = (const GdPostOut *)ctx->h_post.p;
@@ -567,10 +580,10 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		if ((rc = gd_grow(ctx, ctx->m_boxes, sizeof(MapBox) * nb))) return rc;
 		if ((rc = gd_grow(ctx, ctx->m_q, (size_t)qoff[nb] + 64))) return rc;
 		if ((rc = gd_grow(ctx, ctx->m_t, (size_t)toff[nb] + 64))) return rc;
-		if ((rc = gd_grow(ctx, ctx->m_aux, sizeof(int64_t) * (nb + 1) + sizeof(int32_t) * 3 * nb + 64))) return rc;
+		if ((rc = gd_grow(ctx, ctx->m_aux, sizeof(int64_t) * (nb + 1) + sizeof(int32_t) * 3 * nbp + 1024))) return rc;
 		if ((rc = gd_grow(ctx, ctx->m_cig, sizeof(uint32_t) * ((size_t)coff[nb] + 1)))) return rc;
 		int64_t *d_coff = (int64_t *)ctx->m_aux.p;
-		int32_t *d_ex = (int32_t *)(d_coff + nb + 1), *d_score = d_ex + nb, *d_ncig = d_score + nb;
+		int32_t *d_ex = (int32_t *)(((uintptr_t)(d_coff + nb + 1) + 255) & ~(uintptr_t)255), *d_score = d_ex + nbp, *d_ncig = d_score + nbp; // 256-byte aligned, as the host side
 		GD_HIP(hipMemcpyAsync(ctx->m_boxes.p, boxes, sizeof(MapBox) * nb, hipMemcpyHostToDevice, s));
 		GD_HIP(hipMemcpyAsync(d_coff, coff.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, s));
 		GD_HIP(hipMemcpyAsync(d_ex, ex.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
@@ -611,8 +624,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p);
 			GD_HIP(hipMemcpyAsync(ctx->h_post.p, ctx->m_post.p, sizeof(GdPostOut) * (size_t)nb, hipMemcpyDeviceToHost, sd));
 		}
-		GD_HIP(hipMemcpyAsync(h_score, d_score, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
-		GD_HIP(hipMemcpyAsync(h_ncig, d_ncig, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, sd));
+		GD_HIP(hipMemcpyAsync(h_score, d_score, sizeof(int32_t) * 2 * nbp, hipMemcpyDeviceToHost, sd));
 		GD_HIP(gd_stream_wait(ctx, sd));
 	mark("d:wait");
 		// CIGARs are short compared with their capacity (qlen+tlen): pack them on the device, then one copy
