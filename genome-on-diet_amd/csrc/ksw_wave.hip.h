@@ -231,7 +231,7 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 			gdw_compute<DUAL>(L, K, W, pX, pV, pX2, out);
 			store_row(r, out);
 		}
-		L.R += gdw_lo(L.V[0]) - K.B1;
+		L.R += gdw_lo(L.V[0]); // (the bias B1 of every V key is taken off once, after the loop: one sign-extending add per row)
 		if (!ROW_A && (W.en0 & 15) == 0) {
 			const int h = (int)gdw_ror1<LANES>((u32)gdw_track_handoff(L));
 			if (L.blk == W.en_) L.R = h + gdw_lo(L.U[0]);
@@ -251,6 +251,7 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 				pair_row(r, m, std::true_type());
 				pair_row(r + 1, m, std::false_type());
 			}
+			L.R -= (rS - rA) * K.B1; // the trackers of the paired rows accumulated the V keys with their bias (every lane alike, also across the hand-overs)
 			--m; // the band of the last row, for the rows that follow
 			prev_st_ = m >> 4, prev_st0 = m, prev_up = m + (nblkB << 4), prev_en0 = m + w;
 		}
