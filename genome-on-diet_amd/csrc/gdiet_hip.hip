@@ -961,6 +961,9 @@ extern "C" int gdiet_hip_lchain_dp_batch(gdiet_ctx *ctx, int n_reads, const uint
 	return GDIET_OK;
 }
 
+#ifdef GD_SEED_PROF
+extern "C" int gdiet_hip_debug_seed_prof(unsigned long long *out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(gd_seed_prof), 64); }
+#endif
 // ---- read input (input half) ---------------------------------------------------------------------------
 #include "fastx_reader.h"
 struct gdiet_fastx { GdFastx *r; };

@@ -20,6 +20,7 @@ struct MapDevOpt { // uniform per batch
 	GdSrVoteOpt sr;    // ShortReads variant (flag & MM_F_SR)
 	int32_t is_sr;
 	int32_t sort_cap;  // hashes of one read the wave seed kernel sorts in LDS (a power of two; the launch provides 8 B each)
+	uint32_t seed_lds; // dynamic LDS bytes of the wave seed kernel's launch
 	GdPattern pat;
 };
 
@@ -342,6 +343,12 @@ __global__ __launch_bounds__(64) void map_post_kernel(int nb, const MapBox *__re
 #define MAP_SORT_CAP 2048      // hashes of one read the seed kernel sorts in LDS: at least (16 KB) ...
 #define MAP_SORT_CAP_MAX 16384 // ... and at most (128 KB: ONT reads of up to ~180 kbp), chosen per batch from its longest read
 
+#ifdef GD_SEED_PROF
+__device__ unsigned long long gd_seed_prof[8];
+#define GD_PROF_T(i) do { const unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&gd_seed_prof[i], t_ - prof_t); prof_t = t_; } while (0)
+#else
+#define GD_PROF_T(i) do { } while (0)
+#endif
 struct GdEmitLane { // per-lane emission list in scratch
 	GdMini *out;
 	unsigned n, cap;
@@ -355,14 +362,18 @@ struct GdEmitLane { // per-lane emission list in scratch
 
 // parallel sketch of `dl` sparsified bases; the first min(total, cap) minimizers in read order go to dst[0..).
 // Returns (uniform) the count, or ~0u when a scratch list or dst overflowed.
-__device__ unsigned map_par_sketch(const uint8_t *str, unsigned dl, int w, int k, unsigned shift, const GdPattern &P, GdMini *tmp,
+__device__ __forceinline__ unsigned map_par_sketch(const uint8_t *str, unsigned dl, int w, int k, unsigned shift, const GdPattern &P, GdMini *tmp,
                                    unsigned R, GdMini *dst, unsigned dst_cap, uint32_t cap, GdMini *win /* LDS: w x 64 entries, lane-interleaved */)
 {
 	const unsigned lane = threadIdx.x & 63;
 	const unsigned chunk = (dl + 63) / 64;
 	const unsigned i0 = lane * chunk, i1 = i0 + chunk < dl ? i0 + chunk : dl;
 	GdEmitLane e = {tmp + (size_t)lane * R, 0, R};
-	if (chunk && i0 < dl) gd_sketch_slice(str, dl, i0, i1, w, k, 0, shift, P, true, e, win + lane, 64);
+#ifdef GD_SEED_PROF
+	unsigned long long prof_t = wall_clock64();
+#endif
+	if (chunk && i0 < dl) gd_sketch_slice<GdEmitLane, true>(str, dl, i0, i1, w, k, 0, shift, P, true, e, win + lane, 64);
+	GD_PROF_T(6);
 	unsigned incl = e.n;
 	for (int d = 1; d < 64; d <<= 1) {
 		const unsigned v = __shfl_up(incl, d);
@@ -377,6 +388,7 @@ __device__ unsigned map_par_sketch(const uint8_t *str, unsigned dl, int w, int k
 		if (p < dst_cap) dst[p] = e.out[j];
 		else bad = true;
 	}
+	GD_PROF_T(7);
 	return __any(bad) ? ~0u : eff;
 }
 
@@ -400,6 +412,9 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	// dynamic LDS: the winnowing windows of the 64 lanes (w x 64 entries, lane-interleaved), reused by the hash sort of S4
 	extern __shared__ __attribute__((aligned(16))) uint8_t seed_lds[];
 	GdMini *win = reinterpret_cast<GdMini *>(seed_lds);
+#ifdef GD_SEED_PROF
+	unsigned long long prof_t = wall_clock64();
+#endif
 	// S1: mm_sketch2 -- every phase, phase 0 on the cropped read, later phases capped at phase 0's count (LR/sketch.c:2174-2223)
 	unsigned len_crop, total = 0;
 	uint32_t cap;
@@ -416,6 +431,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 		if (cap == UINT32_MAX) len_crop = (unsigned)len, cap = n;
 	}
 	if (bad) { o.n_seeds = -1; if (lane == 0) out[rid] = o; return; }
+	GD_PROF_T(0);
 	// S3: mm_get_shift -- probes in parallel, one sum per phase
 	{
 		unsigned best = 0, base = 0;
@@ -431,6 +447,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 		}
 	}
 	__syncthreads();
+	GD_PROF_T(1);
 	// S2: mm_sketch3 at the chosen phase
 	unsigned n_mv;
 	{
@@ -440,6 +457,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 		if (n_mv == ~0u) { o.n_seeds = -1; if (lane == 0) out[rid] = o; return; }
 		if (O.max_nb_seeds != UINT32_MAX && O.max_nb_seeds > 0 && n_mv == O.max_nb_seeds) o.tel = (uint32_t)(mv[n_mv - 1].y >> 1); // :2010-2012
 	}
+	GD_PROF_T(2);
 	// S4: mm_seed_mz_flt.  It only ever drops something when one hash occurs more than mid_occ times in the read, which a
 	// wavefront bitonic sort of the hashes in LDS decides in a few microseconds (a run longer than mid_occ <=> s[i] == s[i + mid_occ]
 	// for some i); only then -- practically never -- does lane 0 run the sequential filter.  Lists too long for the LDS buffer
@@ -475,12 +493,26 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 			n_mv = __shfl(nn, 0);
 		}
 	}
-	// S5: probes in parallel, then the sequential selection
-	for (unsigned j = lane; j < n_mv; j += 64) gd_collect_probe(I, mv[j], seeds[j]);
+	GD_PROF_T(3);
+	// S5: probes in parallel, then the sequential selection (mm_seed_select's streak logic and the two compactions: three passes of
+	// lane 0 over the seeds, each a dependent load-store chain).  The seeds live in LDS for it when they fit (the sort buffer is idle
+	// by now): ~30 ns per access instead of the ~500 ns of a round trip to global memory -- that chain was most of the kernel's
+	// latency (4.5 k seeds of a 50 kbp ONT read: ~7 ms).  The kept seeds go to their global array in one parallel copy.
+	const bool in_lds = (size_t)n_mv * sizeof(GdSeed) <= (size_t)O.seed_lds;
+	GdSeed *work = in_lds ? reinterpret_cast<GdSeed *>(seed_lds) : seeds;
+	for (unsigned j = lane; j < n_mv; j += 64) gd_collect_probe(I, mv[j], work[j]);
 	__syncthreads();
+	GD_PROF_T(4);
+	int n_kept = 0;
 	if (lane == 0) {
 		o.n_mv = n_mv;
-		o.n_seeds = gd_collect_finish(seeds, (int)n_mv, len, O.mid_occ, O.max_max_occ, O.occ_dist, &o.n_a);
+		o.n_seeds = n_kept = gd_collect_finish(work, (int)n_mv, len, O.mid_occ, O.max_max_occ, O.occ_dist, &o.n_a);
 		out[rid] = o;
 	}
+	if (in_lds) {
+		__syncthreads();
+		n_kept = __shfl(n_kept, 0);
+		for (int j = (int)lane; j < n_kept; j += 64) seeds[j] = work[j];
+	}
+	GD_PROF_T(5);
 }

@@ -229,7 +229,7 @@ extern "C" int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **out, in
 	});
 	t_[2] = gd_now();
 	// stream-ordered allocation: a plain hipMalloc / hipFree per mini-batch synchronises the whole device, i.e. every batch in flight
-	hipError_t e = hipMallocAsync(&b->d_reads, enc_len, ctx->stream);
+	hipError_t e = hipMallocAsync(&b->d_reads, enc_len + 64, ctx->stream); // (slack: the seed kernel reads aligned 8-byte words)
 	if (e == hipSuccess) e = hipMallocAsync(&b->d_roff, sizeof(int64_t) * (n + 1), ctx->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(b->d_reads, b->enc.data(), enc_len, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(b->d_roff, b->roff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream);
@@ -438,6 +438,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	if ((rc = gd_host_grow(ctx, ctx->h_seedout, sizeof(MapSeedOut) * (size_t)n))) return rc;
 	MapSeedOut *so = (MapSeedOut *)ctx->h_seedout.p;
 	const size_t seed_lds = std::max<size_t>((size_t)O.w * 64 * sizeof(GdMini), (size_t)D.sort_cap * sizeof(uint64_t));
+	D.seed_lds = (uint32_t)seed_lds;
 	if (seed_lds > 64 * 1024) GD_HIP(hipFuncSetAttribute((const void *)map_seed_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seed_lds));
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		// one read per thread (the plain sequential form) for short reads -- a 150 bp read has ~75 sparsified bases, far too few to

@@ -9,9 +9,11 @@
 #if defined(__HIPCC__)
 #define GDM_HD __host__ __device__ inline
 #define GDM_HDM __host__ __device__ inline // member functions
+#define GDM_HDI __host__ __device__ __forceinline__ // must be inlined for the address space of its pointer arguments to be seen
 #else
 #define GDM_HD static inline
 #define GDM_HDM inline
+#define GDM_HDI static inline
 #endif
 
 #define GDM_MAX_W 64      // window sizes above this are rejected by the planner (the reference allows < 256)
@@ -71,22 +73,41 @@ GDM_HD unsigned gd_diet_len(const GdPattern &P, unsigned len, unsigned shift)
 // last one and performs the end-of-sequence flush.
 // win / wstride: storage of the w-entry window (entry j at win[j * wstride]); nullptr = a local array.  The wave-parallel device
 // kernels pass lane-interleaved LDS (a dynamically indexed local array lives in scratch memory there, an order of magnitude slower).
-template <class Emit>
-GDM_HD void gd_sketch_range(const uint8_t *str, unsigned i_begin, unsigned i_emit, unsigned i_end, int l_init, bool do_final, int w, int k,
-                            uint32_t rid, unsigned shift, const GdPattern &P, bool final_ge, Emit &emit, GdMini *win = nullptr, int wstride = 1)
+// EXT_WIN (a compile-time choice, and the whole chain force-inlined on the device): with a run-time choice between the caller's
+// LDS window and a local array the window pointer is a generic one -- every access a flat_load / flat_store through the vector
+// memory path (~500 cycles) instead of a ds_read / ds_write (~64), and the local array costs 1 KB of scratch per lane even if unused.
+template <class Emit, bool EXT_WIN = false>
+GDM_HDI void gd_sketch_range(const uint8_t *str, unsigned i_begin, unsigned i_emit, unsigned i_end, int l_init, bool do_final, int w, int k,
+                             uint32_t rid, unsigned shift, const GdPattern &P, bool final_ge, Emit &emit, GdMini *win = nullptr, int wstride = 1)
 {
 	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
 	uint64_t kmer[2] = {0, 0};
-	GdMini own[GDM_MAX_W], mn = {UINT64_MAX, UINT64_MAX};
-	GdMini *const wb = win ? win : own;
-	const int ws = win ? wstride : 1;
+	GdMini own[EXT_WIN ? 1 : GDM_MAX_W], mn = {UINT64_MAX, UINT64_MAX};
+	GdMini *const wb = EXT_WIN ? win : own;
+	const int ws = EXT_WIN ? wstride : 1;
 #define buf(j_) wb[(j_) * ws]
 	int l = l_init, buf_pos = 0, min_pos = 0;
 	for (int j = 0; j < w; ++j) buf(j).x = buf(j).y = UINT64_MAX;
 #define GDM_EMIT(m_) do { if (i >= i_emit) { if (emit(m_)) return; } } while (0)
+	// get_real_location (:20-23) without a division per base: quotient and remainder of i by P.ones carried along; a pattern with
+	// a single 1 (every preset of the reference: "10") needs no table look-up per base
+	unsigned iq = i_begin / P.ones, ir = i_begin % P.ones;
+	const unsigned loc0 = P.ones_loc[0];
+	const bool one_1 = P.ones == 1;
+	// EXT_WIN (the wave-parallel device kernels): the read is fetched eight aligned bytes at a time -- one global load per four
+	// bases of a "10" pattern instead of one per base (the caller's buffer has 8 bytes of slack at its end)
+	uint64_t cache8 = 0;
+	uintptr_t cache_at = ~(uintptr_t)0;
 	for (unsigned i = i_begin; i < i_end; ++i) {
-		const unsigned real = (i / P.ones) * P.W + P.ones_loc[i % P.ones] + shift; // get_real_location, :20-23
-		const int c = str[real] < 4 ? str[real] : 4;
+		const unsigned real = iq * P.W + (one_1 ? loc0 : P.ones_loc[ir]) + shift;
+		if (++ir == P.ones) ir = 0, ++iq;
+		uint8_t sb;
+		if (EXT_WIN) {
+			const uintptr_t a = (uintptr_t)(str + real), al = a & ~(uintptr_t)7;
+			if (al != cache_at) cache8 = *reinterpret_cast<const uint64_t *>(al), cache_at = al;
+			sb = (uint8_t)(cache8 >> (8 * (a & 7)));
+		} else sb = str[real];
+		const int c = sb < 4 ? sb : 4;
 		GdMini info = {UINT64_MAX, UINT64_MAX};
 		if (c < 4) {
 			const int span = l + 1 < k ? l + 1 : k;
@@ -110,16 +131,44 @@ GDM_HD void gd_sketch_range(const uint8_t *str, unsigned i_begin, unsigned i_emi
 			mn = info, min_pos = buf_pos;
 		} else if (buf_pos == min_pos) { // the old minimum left the window
 			if (l >= w + k - 1 && mn.x != UINT64_MAX) GDM_EMIT(mn);
-			mn.x = UINT64_MAX;
-			for (int j = buf_pos + 1; j < w; ++j)
-				if (mn.x >= buf(j).x) mn = buf(j), min_pos = j;
-			for (int j = 0; j <= buf_pos; ++j)
-				if (mn.x >= buf(j).x) mn = buf(j), min_pos = j;
-			if (l >= w + k - 1 && mn.x != UINT64_MAX) { // identical k-mers in the window
-				for (int j = buf_pos + 1; j < w; ++j)
-					if (mn.x == buf(j).x && mn.y != buf(j).y) GDM_EMIT(buf(j));
-				for (int j = 0; j <= buf_pos; ++j)
-					if (mn.x == buf(j).x && mn.y != buf(j).y) GDM_EMIT(buf(j));
+			// rescan in window order (buf_pos+1 .. w-1, 0 .. buf_pos), the LAST of equal minima wins (:2045-2052).  Only the hashes are
+			// read, four independent loads at a time -- in the wave-parallel kernels some lane is here on almost every step, so the
+			// whole wavefront pays this loop's latency per base -- and y once, for the winner.
+			uint64_t bx = UINT64_MAX;
+			int bp = buf_pos + 1 < w ? buf_pos + 1 : 0;
+			for (int t = 0; t < w; t += 4) {
+				uint64_t xs[4];
+				int js[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					int j = buf_pos + 1 + t + q;
+					if (j >= w) j -= w;
+					js[q] = j;
+					xs[q] = t + q < w ? buf(j).x : UINT64_MAX;
+				}
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+					if (t + q < w && bx >= xs[q]) bx = xs[q], bp = js[q];
+			}
+			mn.x = bx, mn.y = buf(bp).y, min_pos = bp;
+			if (l >= w + k - 1 && mn.x != UINT64_MAX) { // identical k-mers in the window (:2053-2089), same order
+				for (int t = 0; t < w; t += 4) {
+					uint64_t xs[4];
+					int js[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						int j = buf_pos + 1 + t + q;
+						if (j >= w) j -= w;
+						js[q] = j;
+						xs[q] = t + q < w ? buf(j).x : UINT64_MAX;
+					}
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+						if (t + q < w && mn.x == xs[q]) {
+							const GdMini d = buf(js[q]);
+							if (mn.y != d.y) GDM_EMIT(d);
+						}
+				}
 			}
 		}
 		if (l == w + k - 1 && mn.x != UINT64_MAX) { // first full window: identical k-mers were not written yet
@@ -144,9 +193,9 @@ GDM_HD void gd_sketch_core(const uint8_t *str, unsigned diet_len, int w, int k, 
 
 // slice [i_emit, i_end) of a sketch over diet_len sparsified bases: finds the warm-up start and the run length of non-N
 // bases in front of it, then runs the automaton (see gd_sketch_range)
-template <class Emit>
-GDM_HD void gd_sketch_slice(const uint8_t *str, unsigned diet_len, unsigned i_emit, unsigned i_end, int w, int k, uint32_t rid,
-                            unsigned shift, const GdPattern &P, bool final_ge, Emit &emit, GdMini *win = nullptr, int wstride = 1)
+template <class Emit, bool EXT_WIN = false>
+GDM_HDI void gd_sketch_slice(const uint8_t *str, unsigned diet_len, unsigned i_emit, unsigned i_end, int w, int k, uint32_t rid,
+                             unsigned shift, const GdPattern &P, bool final_ge, Emit &emit, GdMini *win = nullptr, int wstride = 1)
 {
 	const unsigned wu = (unsigned)(w + k);
 	const unsigned i_begin = i_emit > wu ? i_emit - wu : 0;
@@ -159,7 +208,7 @@ GDM_HD void gd_sketch_slice(const uint8_t *str, unsigned diet_len, unsigned i_em
 			++l0;
 		}
 	}
-	gd_sketch_range(str, i_begin, i_emit, i_end, l0, i_end >= diet_len, w, k, rid, shift, P, final_ge, emit, win, wstride);
+	gd_sketch_range<Emit, EXT_WIN>(str, i_begin, i_emit, i_end, l0, i_end >= diet_len, w, k, rid, shift, P, final_ge, emit, win, wstride);
 }
 
 // ---- flat index view (device mirror of mm_idx_t's buckets; built by map_index.h) -------------------------------

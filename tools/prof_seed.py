@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Where the wave seed kernel spends its time: run a bench tool in-process with a library built with -DGD_SEED_PROF (wall_clock64
+stamps between the kernel's phases, summed over wavefronts) and print the shares.
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread -DGD_SEED_PROF -o /tmp/libgdiet_prof.so genome-on-diet_amd/csrc/gdiet_hip.hip -lz
+    GDIET_HIP_LIB=/tmp/libgdiet_prof.so python tools/prof_seed.py bench.py --no-cpu-baseline --no-upload-pass --steps 6 --inflight 1
+"""
+import ctypes as C, os, sys, subprocess, runpy
+# run a bench tool in-process with the profiling library, then read the phase counters
+sys.argv = sys.argv[1:]
+import atexit
+def dump():
+    lib = C.CDLL(os.environ["GDIET_HIP_LIB"])
+    a = (C.c_ulonglong * 8)()
+    lib.gdiet_hip_debug_seed_prof(a)
+    tot = sum(a[:6]) or 1
+    print("seed phases (wall_clock64 ticks, summed over wavefronts): S1 sketch2 %.1f%%  S3 shift %.1f%%  S2 sketch3 %.1f%%  S4 flt %.1f%%  S5 probes %.1f%%  S5 select+copy %.1f%%   total %d | inside the sketches: slices %.1f%%, scan+copy %.1f%%" % tuple([100.0 * a[i] / sum(a[:6]) for i in range(6)] + [sum(a[:6]), 100.0 * a[6] / sum(a[:6]), 100.0 * a[7] / sum(a[:6])]), file=sys.stderr)
+atexit.register(dump)
+runpy.run_path(sys.argv[0], run_name="__main__")
