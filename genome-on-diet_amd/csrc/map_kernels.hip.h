@@ -362,24 +362,26 @@ struct GdEmitLane { // per-lane emission list in scratch
 
 // parallel sketch of `dl` sparsified bases; the first min(total, cap) minimizers in read order go to dst[0..).
 // Returns (uniform) the count, or ~0u when a scratch list or dst overflowed.
-__device__ __forceinline__ unsigned map_par_sketch(const uint8_t *str, unsigned dl, int w, int k, unsigned shift, const GdPattern &P, GdMini *tmp,
-                                   unsigned R, GdMini *dst, unsigned dst_cap, uint32_t cap, GdMini *win /* LDS: w x 64 entries, lane-interleaved */)
+// the steps [a, b) of a sketch over dl sparsified bases, 64 exact slices; their minimizers are appended in read order to dst[have..)
+// as long as the list stays below `cap` (0: no cap).  Returns (uniform) the new length, or ~0u when a scratch list or dst overflowed.
+__device__ __forceinline__ unsigned map_par_sketch_range(const uint8_t *str, unsigned dl, unsigned a, unsigned b, int w, int k, unsigned shift, const GdPattern &P,
+                                                         GdMini *tmp, unsigned R, GdMini *dst, unsigned dst_cap, uint32_t cap, unsigned have, GdMini *win)
 {
 	const unsigned lane = threadIdx.x & 63;
-	const unsigned chunk = (dl + 63) / 64;
-	const unsigned i0 = lane * chunk, i1 = i0 + chunk < dl ? i0 + chunk : dl;
+	const unsigned chunk = (b - a + 63) / 64;
+	const unsigned i0 = a + lane * chunk, i1 = i0 + chunk < b ? i0 + chunk : b;
 	GdEmitLane e = {tmp + (size_t)lane * R, 0, R};
 #ifdef GD_SEED_PROF
 	unsigned long long prof_t = wall_clock64();
 #endif
-	if (chunk && i0 < dl) gd_sketch_slice<GdEmitLane, true>(str, dl, i0, i1, w, k, 0, shift, P, true, e, win + lane, 64);
+	if (chunk && i0 < b) gd_sketch_slice<GdEmitLane, true>(str, dl, i0, i1, w, k, 0, shift, P, true, e, win + lane, 64);
 	GD_PROF_T(6);
 	unsigned incl = e.n;
 	for (int d = 1; d < 64; d <<= 1) {
 		const unsigned v = __shfl_up(incl, d);
 		if ((int)lane >= d) incl += v;
 	}
-	const unsigned total = __shfl(incl, 63), off = incl - e.n;
+	const unsigned total = have + __shfl(incl, 63), off = have + incl - e.n;
 	const unsigned eff = (cap > 0 && total >= cap) ? cap : total;
 	bool bad = e.n > R;
 	for (unsigned j = 0; j < e.n && !bad; ++j) {
@@ -390,6 +392,25 @@ __device__ __forceinline__ unsigned map_par_sketch(const uint8_t *str, unsigned 
 	}
 	GD_PROF_T(7);
 	return __any(bad) ? ~0u : eff;
+}
+
+// parallel sketch of `dl` sparsified bases; the first min(total, cap) minimizers in read order go to dst[0..).
+// Returns (uniform) the count, or ~0u on overflow.  With a cap the sequential reference stops at the cap-th minimizer; slices
+// cannot stop each other, so a prefix that should hold it (the expected 2 / (w + 1) minimizers per base, 25 % margin) is sketched
+// first and the rest of the read only if the prefix fell short -- the slices being exact, the first `cap` minimizers are the same
+// either way.  (Phase >= 1 of mm_sketch2 is capped at phase 0's count, found in the first 20 % of a HiFi read: without this the
+// capped pass cost as much as an uncapped one.)
+__device__ __forceinline__ unsigned map_par_sketch(const uint8_t *str, unsigned dl, int w, int k, unsigned shift, const GdPattern &P, GdMini *tmp,
+                                                   unsigned R, GdMini *dst, unsigned dst_cap, uint32_t cap, GdMini *win /* LDS: w x 64 entries, lane-interleaved */)
+{
+	if (cap == 0) return map_par_sketch_range(str, dl, 0, dl, w, k, shift, P, tmp, R, dst, dst_cap, 0, 0, win);
+	uint64_t l1 = (uint64_t)cap * (uint64_t)(w + 1) / 2;
+	l1 += l1 / 4 + (unsigned)(w + k);
+	if (l1 >= dl) return map_par_sketch_range(str, dl, 0, dl, w, k, shift, P, tmp, R, dst, dst_cap, cap, 0, win);
+	const unsigned n1 = map_par_sketch_range(str, dl, 0, (unsigned)l1, w, k, shift, P, tmp, R, dst, dst_cap, cap, 0, win);
+	if (n1 == ~0u || n1 >= cap) return n1;
+	__syncthreads(); // (the lanes' scratch lists and LDS windows are reused)
+	return map_par_sketch_range(str, dl, (unsigned)l1, dl, w, k, shift, P, tmp, R, dst, dst_cap, cap, n1, win);
 }
 
 __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const uint8_t *__restrict__ reads, const int64_t *__restrict__ roff,
@@ -465,7 +486,19 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	if (O.q_occ_frac > 0.0f && (int64_t)n_mv > (int64_t)O.mid_occ && O.mid_occ > 0) {
 		uint64_t *srt = reinterpret_cast<uint64_t *>(seed_lds); // the window storage is idle now
 		bool need = true;
-		if (n_mv <= (unsigned)O.sort_cap) {
+		{ // cheap exact pre-check: count the hashes in buckets (LDS atomics); no bucket above mid_occ => no hash above mid_occ => nothing to drop
+			const unsigned nb = (unsigned)(O.seed_lds / sizeof(uint32_t)) >= 8192u ? 8192u : 4096u; // (the launch provides at least 16 KB)
+			uint32_t *cnt = reinterpret_cast<uint32_t *>(seed_lds);
+			for (unsigned i = lane; i < nb; i += 64) cnt[i] = 0;
+			__syncthreads();
+			for (unsigned i = lane; i < n_mv; i += 64) atomicAdd(&cnt[(unsigned)((mv[i].x >> 8) * 0x9E3779B97F4A7C15ull >> 40) & (nb - 1)], 1u);
+			__syncthreads();
+			bool over = false;
+			for (unsigned i = lane; i < nb; i += 64) over |= cnt[i] > (uint32_t)O.mid_occ;
+			need = __any(over);
+			__syncthreads();
+		}
+		if (need && n_mv <= (unsigned)O.sort_cap) {
 			unsigned P2 = 64;
 			while (P2 < n_mv) P2 <<= 1;
 			for (unsigned i = lane; i < P2; i += 64) srt[i] = i < n_mv ? mv[i].x : UINT64_MAX;
@@ -503,16 +536,53 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
 	for (unsigned j = lane; j < n_mv; j += 64) gd_collect_probe(I, mv[j], work[j]);
 	__syncthreads();
 	GD_PROF_T(4);
+	// gd_collect_finish with its two compactions done by the whole wavefront (ballot + prefix count, in place: a chunk is read into
+	// registers before anything of it is overwritten, and writes never pass the chunk's own positions); only mm_seed_select's streak
+	// logic stays on lane 0, and only for reads that have a seed above max_occ at all
+	int n_m0 = 0;
+	bool any_high = false;
+	for (unsigned b0 = 0; b0 < n_mv; b0 += 64) { // drop the minimizers absent from the index
+		const unsigned j = b0 + lane;
+		GdSeed sd;
+		sd.n = 0;
+		if (j < n_mv) sd = work[j];
+		const bool keep = j < n_mv && sd.n != 0;
+		const uint64_t m = __ballot(keep);
+		any_high |= keep && (int32_t)sd.n > O.mid_occ;
+		__syncthreads();
+		if (keep) work[n_m0 + __popcll(m & ((1ull << lane) - 1))] = sd;
+		n_m0 += __popcll(m);
+		__syncthreads();
+	}
+	if (__any(any_high)) {
+		if (O.occ_dist > 0 && O.max_max_occ > O.mid_occ) {
+			if (lane == 0) gd_seed_select(n_m0, work, len, O.mid_occ, O.max_max_occ, O.occ_dist);
+		} else
+			for (int j = (int)lane; j < n_m0; j += 64)
+				if ((int32_t)work[j].n > O.mid_occ) work[j].flt = 1;
+		__syncthreads();
+	}
 	int n_kept = 0;
+	int64_t n_a = 0;
+	for (int b0 = 0; b0 < n_m0; b0 += 64) { // keep the unfiltered, count their occurrences
+		const int j = b0 + (int)lane;
+		GdSeed sd;
+		sd.n = 0, sd.flt = 1;
+		if (j < n_m0) sd = work[j];
+		const bool keep = j < n_m0 && !sd.flt;
+		const uint64_t m = __ballot(keep);
+		if (keep) n_a += sd.n;
+		__syncthreads();
+		if (keep) work[n_kept + __popcll(m & ((1ull << lane) - 1))] = sd;
+		n_kept += __popcll(m);
+		__syncthreads();
+	}
+	for (int d = 32; d > 0; d >>= 1) n_a += __shfl_xor(n_a, d);
 	if (lane == 0) {
-		o.n_mv = n_mv;
-		o.n_seeds = n_kept = gd_collect_finish(work, (int)n_mv, len, O.mid_occ, O.max_max_occ, O.occ_dist, &o.n_a);
+		o.n_mv = n_mv, o.n_seeds = n_kept, o.n_a = n_a;
 		out[rid] = o;
 	}
-	if (in_lds) {
-		__syncthreads();
-		n_kept = __shfl(n_kept, 0);
+	if (in_lds)
 		for (int j = (int)lane; j < n_kept; j += 64) seeds[j] = work[j];
-	}
 	GD_PROF_T(5);
 }
