@@ -3,7 +3,7 @@
 Not the headline bench (bench.py = configs[3]); same structure, smaller synthetic reference by default.
 
     python tools/bench_variant.py --kind sr  [--batch 262144] [--ref-mbp 400] [--steps 5]
-    python tools/bench_variant.py --kind ont [--batch 9216] [--inflight 2] [--ref-mbp 3088] [--steps 4]
+    python tools/bench_variant.py --kind ont [--batch 9216] [--inflight 3] [--ref-mbp 3088] [--steps 4]
       (9216 reads per batch = three rounds of the 3072 resident wavefronts of the checkpointed wide-band kernel: the long tail of the
       read-length distribution -- a 150 kbp read runs three times as long as the median one -- is then hidden behind the refill)
 """
