@@ -514,6 +514,18 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		size_t at = 0;
 		for (int g : order) for (int32_t id : geos[g].members) ids[k][at++] = id;
 	}
+	// checkpointed wide-band alignments whose band fits a 96-block ring (w = 1300: 83 blocks) go to the form with one block + one half
+	// block per lane; the rest (wider bands) keep two blocks per lane.  Both lists stay longest-first.  GDIET_WIDE_RING=128 forces the latter.
+	size_t n_ring96 = 0;
+	if (wide_ck) {
+		static const bool ring128_only = getenv("GDIET_WIDE_RING") && atoi(getenv("GDIET_WIDE_RING")) == 128;
+		std::vector<int32_t> &v = ids[GD_KIND_WAVE128];
+		if (!ring128_only)
+			n_ring96 = (size_t)(std::stable_partition(v.begin(), v.end(), [&](int32_t id) {
+				const KswTask &A = h_tasks[id];
+				return gd_wave_supported(A.qlen, A.tlen, A.w, 96);
+			}) - v.begin());
+	}
 	// the short-alignment kernels run 4 / 6 / 8 alignments of identical (qlen, tlen, w) per wavefront (groups of 16 / 10 / 8 lanes):
 	// cut the sorted list into such groups, one list per group width (-1 pads an incomplete group)
 	std::vector<int32_t> groups[3]; // [0]: 16 lanes, [1]: 10, [2]: 8
@@ -630,9 +642,11 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		// serial chain; plenty of them: one wavefront each, two blocks per lane, no barrier
 		const int n128 = (int)ids[GD_KIND_WAVE128].size();
 		const bool two = !wide_ck && (ctx->wide_two_waves == 1 || (ctx->wide_two_waves < 0 && n128 < ctx->wave_slots / 2));
-		if (wide_ck)
-			gd_launch_wave128(d_tasks, d_ids + id_off[GD_KIND_WAVE128], n128, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, d_n_cigar, d_cigar, true);
-		else if (two)
+		if (wide_ck) {
+			if (n_ring96) gd_launch_wave96c(d_tasks, d_ids + id_off[GD_KIND_WAVE128], (int)n_ring96, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, d_n_cigar, d_cigar);
+			if ((size_t)n128 > n_ring96)
+				gd_launch_wave128(d_tasks, d_ids + id_off[GD_KIND_WAVE128] + n_ring96, n128 - (int)n_ring96, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, d_n_cigar, d_cigar, true);
+		} else if (two)
 			gd_launch_wave2x64(d_tasks, d_ids + id_off[GD_KIND_WAVE128], n128, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream,
 			                   fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
 		else

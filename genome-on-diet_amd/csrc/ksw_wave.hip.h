@@ -475,6 +475,7 @@ __device__ __forceinline__ void gdw_cone_restore(WaveLane &L, const WaveK &K, co
 	if (blk >= 0) { // ring position blk mod 128 of the first pass: lane (p >> 1), sub-block (p & 1)
 		const int pos = blk & 127;
 		gdw_lane_load(L, ck_chunk + (pos >> 1) + (pos & 1) * 67 * 64);
+		L.tn = (L.Tb[0] | L.Tb[1] | L.Tb[2] | L.Tb[3]) & 0x04040404u; // (recomputed: the two halves of a block of the 96-block ring do not know each other's)
 		have = L.blk == blk; // (else that position held another block at the time: this one had retired, or had not entered the ring)
 	}
 	if (!have) gdw_fresh_block(L, K, blk, r0 > 0 ? r0 - 1 : 0, query, qlen, target, tlen); // (query bytes of row r0 - 1: the row loop shifts first)
@@ -576,6 +577,191 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128c_kernel(const KswTask *
 	gd_walk_finish(Wk, *Tp, tid, n_cigar, cigar, lane);
 }
 
+// ---- the checkpointed form on a 96-block ring: one block + one half block per lane (ksw_wave_core.h, "half blocks") ------------
+// First pass only differs: lane l holds block position l (F) and half (l & 1) of block position 64 + (l >> 1) (H); the ring order is
+// F(0) .. F(63), H(0) .. H(63), back to F(0), so the row r-1 values of "the (half) block below" are one wave_ror:1 of F's and one of
+// H's registers, swapped in lane 0.  Snapshots are written in the 128-position record format of the kernel above (a half block
+// stores its 16-bit halves of the eight registers of each array), so the second pass -- gdw_cone_restore / gdw_cone_row / the walk
+// -- is the very same code.  12 packed registers per state array instead of 16: -25 % instructions in the first pass.
+struct Wave96State {
+	WaveLane F;
+	WaveHalf H;
+	bool any_tn;
+	int prev_st_, prev_st0, prev_up, prev_en0, have_f, Rf;
+};
+
+__device__ __forceinline__ void gdw96_row(Wave96State &S, const WaveK &K, int r, int qlen, int tlen, int w, const uint8_t *query, const uint8_t *target, int lane,
+                                          int mlast, int sl)
+{
+	constexpr int NBLK = 96;
+	WaveLane &F = S.F;
+	WaveHalf &H = S.H;
+	WaveRow W;
+	W.r = r;
+	gdw_band_uniform(r, qlen, tlen, w, W.st0, W.en0);
+	W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+	W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+	const int advanced = W.st_ > S.prev_st_;
+	W.use_array = advanced;
+	W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
+	W.set_tr = (W.en0 | 15) >= r;
+	W.ukey = gdw_edge_key(K, r);
+	// (1) row r-1 values of the (half) block below, taken before anything is touched
+	const bool l0 = lane == 0;
+	const u32 aX = gdw_ror1<64>(F.X[7]), aV = gdw_ror1<64>(F.V[7]), aX2 = gdw_ror1<64>(F.X2[7]), aQ = gdw_ror1<64>(F.Qc[3]);
+	const u32 bX = gdw_ror1<64>(H.X[3]), bV = gdw_ror1<64>(H.V[3]), bX2 = gdw_ror1<64>(H.X2[3]), bQ = gdw_ror1<64>(H.Qc[1]);
+	const u32 fX = l0 ? bX : aX, fV = l0 ? bV : aV, fX2 = l0 ? bX2 : aX2, fQ = l0 ? bQ : aQ;
+	const u32 hX = l0 ? aX : bX, hV = l0 ? aV : bV, hX2 = l0 ? aX2 : bX2, hQ = l0 ? aQ : bQ;
+	// (2) query window advance; what fell below the window takes over block +96
+	if (r > 0) {
+		const u32 seam = gdw_seam_byte(query, qlen, r - (S.prev_st_ << 4));
+		gdw_shift_query(F, fQ, F.blk == S.prev_st_, seam);
+		gdw_shift_query_half(H, hQ, H.blk == S.prev_st_ && H.half == 0, seam);
+	}
+	if (advanced) {
+		if (F.blk < W.st_) gdw_load_block(F, K, F.blk + NBLK, r, query, qlen, target, tlen);
+		if (H.blk < W.st_) gdw_load_half(H, K, H.blk + NBLK, H.half, r, query, qlen, target, tlen);
+		S.any_tn = __builtin_amdgcn_ballot_w64((F.tn | H.tn) != 0) != 0;
+	}
+	// (3) scalar fix-ups and the score row
+	if (W.set_tr) gdw_reset_tr(F, K, W), gdw_reset_tr_half(H, K, W);
+	if (W.st0 != S.prev_st0 || W.up != S.prev_up || advanced) gdw_make_sel(F, W.st0, W.up), gdw_make_sel_half(H, W.st0, W.up);
+	gdw_update_scores(F, K, S.any_tn);
+	gdw_update_scores_half(H, K, S.any_tn);
+	// (4) DP cells of what lies inside the reference's 16-aligned window
+	if (F.blk <= W.en_) {
+		u32 out[4];
+		gdw_compute(F, K, W, fX, fV, fX2, out); // (the flag / direction bytes are dead code here)
+	}
+	if (H.blk <= W.en_) gdw_compute_half(H, K, W, hX, hV, hX2);
+	// (5) score trackers
+	if (r == 0) F.R = gdw_lo(F.V[0]) - K.B1 - K.qe8, H.R = gdw_lo(H.V[0]) - K.B1 - K.qe8;
+	else F.R += gdw_lo(F.V[0]) - K.B1, H.R += gdw_lo(H.V[0]) - K.B1;
+	if (r > 0 && W.en0 != S.prev_en0 && (W.en0 & 7) == 0) { // a block, or the second half of one, enters the band
+		const int ha = (int)gdw_ror1<64>((u32)gdw_track_handoff(F)), hb = (int)gdw_ror1<64>((u32)gdw_track_handoff_half(H));
+		const int hf = l0 ? hb : ha, hh = l0 ? ha : hb;
+		if ((W.en0 & 15) == 0) {
+			if (F.blk == W.en_) F.R = hf + gdw_lo(F.U[0]);
+			if (H.blk == W.en_ && H.half == 0) H.R = hh + gdw_lo(H.U[0]);
+		} else if (H.blk == W.en_ && H.half == 1) H.R = hh + gdw_lo(H.U[0]);
+	}
+	if (W.en0 == tlen - 1) {
+		if (F.blk == mlast) {
+			if (!S.have_f) S.Rf = gdw_track_to_slot(F, sl);
+			else S.Rf += gdw_cell(F.V, sl) - K.B1;
+		}
+		if (H.blk == mlast && H.half == (sl >> 3)) {
+			if (!S.have_f) S.Rf = gdw_track_to_slot_half(H, sl & 7);
+			else S.Rf += gdw_cell_half(H.V, sl & 7) - K.B1;
+		}
+		S.have_f = 1;
+	}
+	S.prev_st_ = W.st_, S.prev_st0 = W.st0, S.prev_up = W.up, S.prev_en0 = W.en0;
+}
+
+// a snapshot in the record format gdw_cone_restore reads: the record of ring position p = blk mod 128 sits at column p >> 1, field
+// offset (p & 1) * 67; a half block writes its 16-bit halves of the packed registers and its two dwords of the byte arrays
+__device__ __forceinline__ void gdw96_save(const Wave96State &S, u32 *ck_chunk /* lane 0 */, int lane)
+{
+	{
+		const int pos = S.F.blk & 127;
+		gdw_lane_save(S.F, ck_chunk + (pos >> 1) + (pos & 1) * 67 * 64);
+	}
+	const WaveHalf &H = S.H;
+	const int pos = H.blk & 127;
+	u32 *d = ck_chunk + (pos >> 1) + (pos & 1) * 67 * 64;
+	uint16_t *d16 = reinterpret_cast<uint16_t *>(d) + H.half; // low / high 16 bits of every dword
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		d16[(size_t)(k) * 128] = (uint16_t)gdw_half_cell16(H.U, k), d16[(size_t)(8 + k) * 128] = (uint16_t)gdw_half_cell16(H.V, k);
+		d16[(size_t)(16 + k) * 128] = (uint16_t)gdw_half_cell16(H.X, k), d16[(size_t)(24 + k) * 128] = (uint16_t)gdw_half_cell16(H.Y, k);
+		d16[(size_t)(32 + k) * 128] = (uint16_t)gdw_half_cell16(H.X2, k), d16[(size_t)(40 + k) * 128] = (uint16_t)gdw_half_cell16(H.Y2, k);
+	}
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		const int gg = 2 * H.half + g;
+		d[(48 + gg) * 64] = H.Sb[g], d[(52 + gg) * 64] = H.Tb[g], d[(56 + gg) * 64] = H.Qc[g], d[(60 + gg) * 64] = H.SEL[g];
+	}
+	d[65 * 64] = (u32)H.blk;
+	if (H.half == 0) d[66 * 64] = (u32)H.R;
+	// the 32 ring positions nobody holds: their records must not look like a block (gdw_cone_restore compares the block number)
+	if (lane < 32) {
+		const int top = __builtin_amdgcn_readfirstlane(S.prev_st_) + 96 + lane; // (S.prev_st_ <= every held block < S.prev_st_ + 96 at a snapshot)
+		const int p2 = top & 127;
+		ck_chunk[(p2 >> 1) + (p2 & 1) * 67 * 64 + 65 * 64] = 0xffffffffu;
+	}
+}
+
+__global__ __launch_bounds__(128) void ksw_extd2_wave96c_kernel(const KswTask *__restrict__ tasks,
+                                                                const int32_t *__restrict__ task_ids, int n_tasks,
+                                                                const uint8_t *__restrict__ qseq,
+                                                                const uint8_t *__restrict__ tseq,
+                                                                uint8_t *__restrict__ bt, int32_t *__restrict__ status,
+                                                                int32_t *__restrict__ score_out, WaveK K,
+                                                                int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
+{
+	const int lane = threadIdx.x & 63;
+	const int slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+	if (slot >= n_tasks) return;
+	const int tid = __builtin_amdgcn_readfirstlane(task_ids[slot]);
+	if (__builtin_amdgcn_readfirstlane(status[tid]) != GD_ST_PENDING) return;
+	const KswTask *Tp = tasks + tid;
+	const int qlen = __builtin_amdgcn_readfirstlane(Tp->qlen), tlen = __builtin_amdgcn_readfirstlane(Tp->tlen);
+	int w = __builtin_amdgcn_readfirstlane(Tp->w);
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const uint8_t *query = qseq + Tp->qoff, *target = tseq + Tp->toff;
+	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+	const int n_ck = (rend + GD_CK_ROWS) / GD_CK_ROWS;
+	u32 *ck = reinterpret_cast<u32 *>(bt + Tp->bt_off);
+	uint8_t *chunk = bt + Tp->bt_off + (size_t)n_ck * GD_CK_REGS * 64 * 4;
+
+	// ---- pass 1: state and score on the 96-block ring, a snapshot at the start of every chunk ----
+	{
+		Wave96State S;
+		gdw_load_block(S.F, K, lane, 0, query, qlen, target, tlen);
+		gdw_load_half(S.H, K, 64 + (lane >> 1), lane & 1, 0, query, qlen, target, tlen);
+		S.any_tn = __builtin_amdgcn_ballot_w64((S.F.tn | S.H.tn) != 0) != 0;
+		S.prev_st_ = 0, S.prev_st0 = -1, S.prev_up = -1, S.prev_en0 = -1, S.have_f = 0, S.Rf = 0;
+		int ck_row = 0, ck_idx = 0;
+		for (int r = 0; r <= rend; ++r) {
+			if (r == ck_row) {
+				gdw96_save(S, ck + (size_t)ck_idx * GD_CK_REGS * 64, lane);
+				ck_row += GD_CK_ROWS, ++ck_idx;
+			}
+			gdw96_row(S, K, r, qlen, tlen, w, query, target, lane, mlast, sl);
+		}
+		if (S.F.blk == mlast || (S.H.blk == mlast && S.H.half == (sl >> 3))) {
+			score_out[tid] = S.Rf >> 3;
+			status[tid] = GD_ST_TRACED;
+		}
+	}
+	// ---- pass 2: as in ksw_extd2_wave128c_kernel ----
+	GdWalk Wk;
+	gd_walk_init(Wk, qlen, tlen);
+	WaveLane L;
+	for (int kk = n_ck - 1; kk >= 0 && Wk.i >= 0 && Wk.j >= 0; --kk) {
+		const int k = __builtin_amdgcn_readfirstlane(kk);
+		const int i1 = __builtin_amdgcn_readfirstlane(Wk.i), rtop = i1 + __builtin_amdgcn_readfirstlane(Wk.j);
+		const int r0 = k * GD_CK_ROWS;
+		if (rtop < r0) continue;
+		const int r1 = rtop < r0 + GD_CK_ROWS - 1 ? rtop : r0 + GD_CK_ROWS - 1;
+		const int b0 = (i1 >> 4) - 63;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+		gdw_cone_restore(L, K, ck + (size_t)k * GD_CK_REGS * 64, b0 + lane, r0, query, qlen, target, tlen);
+		const bool any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0;
+		int prev_st_ = 0, prev_st0 = -1, prev_up = -1;
+		if (r0 > 0) {
+			int st0, en0;
+			gdw_band_uniform(r0 - 1, qlen, tlen, w, st0, en0);
+			prev_st_ = st0 >> 4, prev_st0 = st0, prev_up = st0 + (((en0 - st0 + 16) >> 4) << 4);
+		}
+		for (int r = r0; r <= r1; ++r) gdw_cone_row(L, K, any_tn, r, qlen, tlen, w, query, b0, lane, prev_st_, prev_st0, prev_up, chunk + (size_t)(r - r0) * 1024);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+		gd_walk_rows(Wk, *Tp, chunk, r0, qlen, tlen, w, cigar, lane, 1024, b0);
+	}
+	gd_walk_finish(Wk, *Tp, tid, n_cigar, cigar, lane);
+}
+
 static inline void gd_launch_wave128(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
                                      uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int32_t *n_cigar = nullptr,
                                      uint32_t *cigar = nullptr, bool checkpointed = false /* needs n_cigar / cigar: it walks its own alignments back */)
@@ -584,6 +770,14 @@ static inline void gd_launch_wave128(const KswTask *tasks, const int32_t *ids, i
 	gdw_make_consts(C, K);
 	if (checkpointed) hipLaunchKernelGGL(ksw_extd2_wave128c_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 	else hipLaunchKernelGGL(ksw_extd2_wave128_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+}
+
+static inline void gd_launch_wave96c(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t, uint8_t *bt, int32_t *status,
+                                     int32_t *score, KswConst C, hipStream_t s, int32_t *n_cigar, uint32_t *cigar)
+{
+	WaveK K;
+	gdw_make_consts(C, K);
+	hipLaunchKernelGGL(ksw_extd2_wave96c_kernel, dim3((n + 1) / 2), dim3(128), 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 }
 
 // ---- wide bands, few alignments: TWO wavefronts per alignment ----------------------------------------------------------------

@@ -436,3 +436,138 @@ static inline bool gd_wave_geometry_ok(int qlen, int tlen, int w, int lanes)
 	}
 	return true;
 }
+
+// ---- half blocks (wide bands on a 96-block ring: ksw_extd2_wave96c_kernel) -------------------------------------------------------
+// A band of w = 1300 has 83 blocks in flight.  On the 128-position ring (two blocks per lane) 36 % of the lanes idle; here a lane
+// holds ONE block of ring positions 0..63 plus HALF a block (8 cells) of positions 64..95 -- twelve packed registers per state
+// array instead of sixteen, 86 % of them busy.  A half block keeps its 8 cells as 4 packed registers, register j = cells (j, j+4), so
+// "cell t-1" is again the register before (j = 0: the incoming dword of the half / block below).  Both halves of a block are inside
+// or outside the reference's 16-aligned window together; everything that is defined per cell (which scores are rewritten, the
+// reset of cell t == r, the boundary scalars of the first computed cell) carries over with the half's first target position
+// tb = 16 * blk + 8 * half.
+struct WaveHalf {
+	u32 U[4], V[4], X[4], Y[4], X2[4], Y2[4];
+	u32 Sb[2], Tb[2], Qc[2], SEL[2];
+	u32 tn;
+	int32_t blk, half;
+	int32_t R; // 8*H(r, tb): score tracker at the half's first cell
+};
+
+GDW_HD void gdw_load_half(WaveHalf &H, const WaveK &K, int m, int half, int r, const uint8_t *query, int qlen, const uint8_t *target, int tlen)
+{
+	H.blk = m, H.half = half;
+	const int tb = (m << 4) + (half << 3);
+#pragma unroll
+	for (int k = 0; k < 4; ++k) H.U[k] = K.uv0, H.V[k] = K.uv0, H.X[k] = K.cx, H.Y[k] = K.cy, H.X2[k] = K.cx2, H.Y2[k] = K.cy2;
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		u32 tw = 0, qw = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int t = tb + 4 * g + b;
+			tw |= (t < tlen ? (u32)target[t] : 0u) << (8 * b);
+			qw |= gdw_qbyte(query, qlen, r - t) << (8 * b);
+		}
+		H.Tb[g] = tw, H.Qc[g] = qw, H.Sb[g] = K.s0, H.SEL[g] = 0x03020100u;
+	}
+	H.tn = (H.Tb[0] | H.Tb[1]) & 0x04040404u;
+	H.R = 0;
+}
+
+GDW_HD void gdw_make_sel_half(WaveHalf &H, int st0, int up)
+{
+	const int tb = (H.blk << 4) + (H.half << 3);
+	int lo = st0 - tb, hi = up - tb;
+	lo = lo < 0 ? 0 : lo > 8 ? 8 : lo;
+	hi = hi < 0 ? 0 : hi > 8 ? 8 : hi;
+	const u32 bm = hi > lo ? (((1u << (hi - lo)) - 1u) << lo) : 0u;
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		const u32 n = (bm >> (4 * g)) & 15u;
+		const u32 spread = (n * 0x00204081u) & 0x01010101u;
+		H.SEL[g] = 0x03020100u + (spread << 2);
+	}
+}
+
+GDW_HD void gdw_shift_query_half(WaveHalf &H, u32 below, bool is_lowest, u32 seam)
+{
+	const u32 in = is_lowest ? (seam << 24) : below;
+	H.Qc[1] = gdw_alignbyte(H.Qc[1], H.Qc[0], 3);
+	H.Qc[0] = gdw_alignbyte(H.Qc[0], in, 3);
+}
+
+GDW_HD void gdw_update_scores_half(WaveHalf &H, const WaveK &K, bool any_tn)
+{
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		u32 x = H.Tb[g] ^ H.Qc[g];
+		if (any_tn) x |= H.Tb[g] & ~(H.Qc[g] << 1) & 0x04040404u;
+		H.Sb[g] = gdw_perm(gdw_perm(K.lut_hi, K.lut_lo, x), H.Sb[g], H.SEL[g]);
+	}
+}
+
+GDW_HD void gdw_reset_tr_half(WaveHalf &H, const WaveK &K, const WaveRow &W)
+{
+	if (H.blk != (W.r >> 4) || H.half != ((W.r >> 3) & 1)) return;
+	const int c = W.r & 7, k = c & 3;
+	const u32 mask = (c & 4) ? 0xffff0000u : 0x0000ffffu;
+	const u32 uk = gdw_pack2(W.ukey);
+#pragma unroll
+	for (int kk = 0; kk < 4; ++kk)
+		if (kk == k) {
+			H.U[kk] = gdw_bfi(mask, uk, H.U[kk]);
+			H.Y[kk] = gdw_bfi(mask, K.cy, H.Y[kk]);
+			H.Y2[kk] = gdw_bfi(mask, K.cy2, H.Y2[kk]);
+		}
+}
+
+// one anti-diagonal of an ACTIVE half block, state and score only (no backtrace: the first pass of the checkpointed form).
+// pX / pV / pX2: the last packed register of X / V / X2 of the (half) block below, row r-1 values.
+GDW_HD void gdw_compute_half(WaveHalf &H, const WaveK &K, const WaveRow &W, u32 pX, u32 pV, u32 pX2)
+{
+	if (!W.use_array) {
+		const u32 first = (H.blk == W.st_ && H.half == 0) ? ~0u : 0u;
+		pX = gdw_bfi_s(first, K.cx, pX), pV = gdw_bfi_s(first, gdw_pack2(W.v1key), pV), pX2 = gdw_bfi_s(first, K.cx2, pX2);
+	}
+	const u32 inX = gdw_alignbit(H.X[3], pX, 16), inV = gdw_alignbit(H.V[3], pV, 16), inX2 = gdw_alignbit(H.X2[3], pX2, 16);
+#pragma unroll
+	for (int k = 3; k >= 0; --k) {
+		const u32 xin = k ? H.X[k - 1] : inX, vin = k ? H.V[k - 1] : inV, x2in = k ? H.X2[k - 1] : inX2;
+		const u32 sk = gdw_perm(H.Sb[1], H.Sb[0], 0x0c000c00u | (u32)k | (u32)(4 + k) << 16);
+		const u32 a = pk_add(xin, vin), b = pk_add(H.Y[k], H.U[k]);
+		const u32 a2 = pk_add(x2in, vin), b2 = pk_add(H.Y2[k], H.U[k]);
+		const u32 zk = pk_max(pk_max(pk_max(sk, a), b), pk_add(pk_max(a2, b2), K.c2));
+		const u32 z8 = pk_min(zk & 0xfff8fff8u, K.zmax);
+		const u32 nV = pk_sub(z8, H.U[k]), nU = pk_sub(z8, vin);
+		const u32 tE = pk_sub(z8, K.te), tE2 = pk_sub(z8, K.te2);
+		H.X[k] = pk_max(pk_sub(a, tE), K.cx), H.Y[k] = pk_max(pk_sub(b, tE), K.cy);
+		H.X2[k] = pk_max(pk_sub(a2, tE2), K.cx2), H.Y2[k] = pk_max(pk_sub(b2, tE2), K.cy2);
+		H.U[k] = nU, H.V[k] = nV;
+	}
+}
+
+GDW_HD int gdw_sum8(const u32 A[4])
+{
+	const u32 s = pk_add(pk_add(A[0], A[1]), pk_add(A[2], A[3]));
+	return gdw_lo(s) + gdw_hi(s);
+}
+// what a half block contributes to the tracker of the (half) block above it: 8*H(r, tb + 8) = 8*H(r, tb) + sum_{i=1..7} U_i - sum_{i=0..7} V_i [+ U_0 there]
+GDW_HD int gdw_track_handoff_half(const WaveHalf &H) { return H.R + gdw_sum8(H.U) - gdw_lo(H.U[0]) - gdw_sum8(H.V); }
+// key of cell `slot` (0..7) of a half's packed array
+GDW_HD int gdw_cell_half(const u32 A[4], int slot)
+{
+	u32 v = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+		if (k == (slot & 3)) v = A[k];
+	return (slot & 4) ? gdw_hi(v) : gdw_lo(v);
+}
+GDW_HD int gdw_track_to_slot_half(const WaveHalf &H, int sl)
+{
+	int acc = H.R;
+	for (int i = 0; i < sl; ++i) acc += gdw_cell_half(H.U, i + 1) - gdw_cell_half(H.V, i);
+	return acc;
+}
+// The snapshots keep the 16-cell layout of WaveLane (register k = cells (k, k+8)) whatever held the block: a half block provides
+// the low (half 0) or high (half 1) 16 bits of the eight registers of each array -- cell k of the half is this value.
+GDW_HD u32 gdw_half_cell16(const u32 A[4], int k) { return (k & 4) ? (A[k & 3] >> 16) : (A[k & 3] & 0xffffu); }

@@ -147,7 +147,113 @@ static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_
 // of all positions every CK rows; pass 2 = per chunk, from the last one down, the CONE of the walk recomputed by 64 lanes holding the
 // blocks [b0, b0 + 63] (gdw_cone_restore / gdw_cone_row on the device) and consumed by a resumable walk.  A cell the walk reads
 // that the cone pass did not compute is an error.
-static EmuResult emulate_ckpt(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int w, const KswConst &C, int CK)
+// pass 1 on the 96-block ring (ksw_extd2_wave96c_kernel / gdw96_row, statement by statement): 64 lanes, each one block (F) and one
+// half block (H); snapshots in the 128-position record format (gdw96_save)
+static int pass1_ring96(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int w, const WaveK &K, int CK, std::vector<std::vector<WaveLane>> &snap)
+{
+	const int rend = qlen + tlen - 2, mlast = (tlen - 1) >> 4, sl = (tlen - 1) & 15;
+	std::vector<WaveLane> F(64);
+	std::vector<WaveHalf> H(64);
+	for (int l = 0; l < 64; ++l) gdw_load_block(F[l], K, l, 0, query, qlen, target, tlen), gdw_load_half(H[l], K, 64 + (l >> 1), l & 1, 0, query, qlen, target, tlen);
+	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
+	for (int r = 0; r <= rend; ++r) {
+		if (r % CK == 0) { // gdw96_save
+			std::vector<WaveLane> rec(128);
+			for (auto &x : rec) memset(&x, 0xEE, sizeof(x)); // (records nobody writes hold whatever was there)
+			for (int l = 0; l < 64; ++l) {
+				rec[F[l].blk & 127] = F[l];
+				WaveLane &d = rec[H[l].blk & 127];
+				const int h = H[l].half;
+				for (int k = 0; k < 8; ++k) {
+					const u32 m = h ? 0x0000ffffu : 0xffff0000u;
+					const int sh = h ? 16 : 0;
+					d.U[k] = (d.U[k] & m) | gdw_half_cell16(H[l].U, k) << sh, d.V[k] = (d.V[k] & m) | gdw_half_cell16(H[l].V, k) << sh;
+					d.X[k] = (d.X[k] & m) | gdw_half_cell16(H[l].X, k) << sh, d.Y[k] = (d.Y[k] & m) | gdw_half_cell16(H[l].Y, k) << sh;
+					d.X2[k] = (d.X2[k] & m) | gdw_half_cell16(H[l].X2, k) << sh, d.Y2[k] = (d.Y2[k] & m) | gdw_half_cell16(H[l].Y2, k) << sh;
+				}
+				for (int g = 0; g < 2; ++g) d.Sb[2 * h + g] = H[l].Sb[g], d.Tb[2 * h + g] = H[l].Tb[g], d.Qc[2 * h + g] = H[l].Qc[g], d.SEL[2 * h + g] = H[l].SEL[g];
+				d.blk = H[l].blk;
+				if (h == 0) d.R = H[l].R;
+			}
+			for (int l = 0; l < 32; ++l) rec[(prev_st_ + 96 + l) & 127].blk = -1;
+			snap.push_back(rec);
+		}
+		WaveRow W;
+		W.r = r;
+		gd_band(r, qlen, tlen, w, W.st0, W.en0);
+		W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+		W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+		const int advanced = W.st_ > prev_st_;
+		W.use_array = advanced, W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open, W.set_tr = (W.en0 | 15) >= r, W.ukey = gdw_edge_key(K, r);
+		u32 fX[64], fV[64], fX2[64], fQ[64], hX[64], hV[64], hX2[64], hQ[64];
+		for (int l = 0; l < 64; ++l) {
+			const int p = (l + 63) % 64;
+			const u32 aX = F[p].X[7], aV = F[p].V[7], aX2 = F[p].X2[7], aQ = F[p].Qc[3], bX = H[p].X[3], bV = H[p].V[3], bX2 = H[p].X2[3], bQ = H[p].Qc[1];
+			const bool l0 = l == 0;
+			fX[l] = l0 ? bX : aX, fV[l] = l0 ? bV : aV, fX2[l] = l0 ? bX2 : aX2, fQ[l] = l0 ? bQ : aQ;
+			hX[l] = l0 ? aX : bX, hV[l] = l0 ? aV : bV, hX2[l] = l0 ? aX2 : bX2, hQ[l] = l0 ? aQ : bQ;
+		}
+		bool reloaded = false;
+		for (int l = 0; l < 64; ++l) {
+			if (r > 0) {
+				const u32 seam = gdw_qbyte(query, qlen, r - (prev_st_ << 4));
+				gdw_shift_query(F[l], fQ[l], F[l].blk == prev_st_, seam);
+				gdw_shift_query_half(H[l], hQ[l], H[l].blk == prev_st_ && H[l].half == 0, seam);
+			}
+			if (F[l].blk < W.st_) gdw_load_block(F[l], K, F[l].blk + 96, r, query, qlen, target, tlen), reloaded = true;
+			if (H[l].blk < W.st_) gdw_load_half(H[l], K, H[l].blk + 96, H[l].half, r, query, qlen, target, tlen), reloaded = true;
+		}
+		if (reloaded != (advanced != 0) && reloaded) { fprintf(stderr, "ring96: reload without an advance\n"); exit(2); }
+		bool any_tn = false;
+		for (int l = 0; l < 64; ++l) any_tn |= (F[l].tn | H[l].tn) != 0;
+		const int remask = W.st0 != prev_st0 || W.up != prev_up || advanced;
+		for (int l = 0; l < 64; ++l) {
+			if (W.set_tr) gdw_reset_tr(F[l], K, W), gdw_reset_tr_half(H[l], K, W);
+			if (remask) gdw_make_sel(F[l], W.st0, W.up), gdw_make_sel_half(H[l], W.st0, W.up);
+			gdw_update_scores(F[l], K, any_tn);
+			gdw_update_scores_half(H[l], K, any_tn);
+		}
+		for (int l = 0; l < 64; ++l) {
+			if (F[l].blk <= W.en_) {
+				u32 out[4];
+				gdw_compute<true>(F[l], K, W, fX[l], fV[l], fX2[l], out);
+			}
+			if (H[l].blk <= W.en_) gdw_compute_half(H[l], K, W, hX[l], hV[l], hX2[l]);
+		}
+		for (int l = 0; l < 64; ++l) {
+			if (r == 0) F[l].R = gdw_lo(F[l].V[0]) - K.B1 - K.qe8, H[l].R = gdw_lo(H[l].V[0]) - K.B1 - K.qe8;
+			else F[l].R += gdw_lo(F[l].V[0]) - K.B1, H[l].R += gdw_lo(H[l].V[0]) - K.B1;
+		}
+		if (r > 0 && W.en0 != prev_en0 && (W.en0 & 7) == 0) {
+			int ha[64], hb[64];
+			for (int l = 0; l < 64; ++l) ha[l] = gdw_track_handoff(F[(l + 63) % 64]), hb[l] = gdw_track_handoff_half(H[(l + 63) % 64]);
+			for (int l = 0; l < 64; ++l) {
+				const int hf = l == 0 ? hb[l] : ha[l], hh = l == 0 ? ha[l] : hb[l];
+				if ((W.en0 & 15) == 0) {
+					if (F[l].blk == W.en_) F[l].R = hf + gdw_lo(F[l].U[0]);
+					if (H[l].blk == W.en_ && H[l].half == 0) H[l].R = hh + gdw_lo(H[l].U[0]);
+				} else if (H[l].blk == W.en_ && H[l].half == 1) H[l].R = hh + gdw_lo(H[l].U[0]);
+			}
+		}
+		if (W.en0 == tlen - 1) {
+			for (int l = 0; l < 64; ++l) {
+				if (F[l].blk == mlast) {
+					if (!have_f) Rf = gdw_track_to_slot(F[l], sl);
+					else Rf += gdw_cell(F[l].V, sl) - K.B1;
+				}
+				if (H[l].blk == mlast && H[l].half == (sl >> 3)) {
+					if (!have_f) Rf = gdw_track_to_slot_half(H[l], sl & 7);
+					else Rf += gdw_cell_half(H[l].V, sl & 7) - K.B1;
+				}
+			}
+			have_f = 1;
+		}
+		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
+	}
+	return Rf;
+}
+
+static EmuResult emulate_ckpt(const uint8_t *query, int qlen, const uint8_t *target, int tlen, int w, const KswConst &C, int CK, bool ring96 = false)
 {
 	const int LANES = 128;
 	WaveK K;
@@ -158,7 +264,8 @@ static EmuResult emulate_ckpt(const uint8_t *query, int qlen, const uint8_t *tar
 	std::vector<std::vector<WaveLane>> snap;
 	for (int l = 0; l < LANES; ++l) gdw_load_block(L[l], K, l, 0, query, qlen, target, tlen);
 	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
-	for (int r = 0; r <= rend; ++r) { // pass 1 (the row loop of emulate(), nothing stored)
+	if (ring96) Rf = pass1_ring96(query, qlen, target, tlen, w, K, CK, snap);
+	for (int r = 0; r <= rend && !ring96; ++r) { // pass 1 (the row loop of emulate(), nothing stored)
 		if (r % CK == 0) snap.push_back(L);
 		WaveRow W;
 		W.r = r;
@@ -221,7 +328,10 @@ static EmuResult emulate_ckpt(const uint8_t *query, int qlen, const uint8_t *tar
 		for (int l = 0; l < 64; ++l) {
 			const int blk = b0 + l;
 			bool have = false;
-			if (blk >= 0) Cn[l] = snap[k][blk & 127], have = Cn[l].blk == blk;
+			if (blk >= 0) {
+				Cn[l] = snap[k][blk & 127], have = Cn[l].blk == blk;
+				Cn[l].tn = (Cn[l].Tb[0] | Cn[l].Tb[1] | Cn[l].Tb[2] | Cn[l].Tb[3]) & 0x04040404u; // (as gdw_cone_restore)
+			}
 			if (!have) gdw_fresh_block(Cn[l], K, blk, r0 > 0 ? r0 - 1 : 0, query, qlen, target, tlen);
 		}
 		bool any_tn = false;
@@ -311,7 +421,8 @@ int main(int argc, char **argv)
 	const unsigned seed = argc > 1 ? atoi(argv[1]) : 1;
 	const int n = argc > 2 ? atoi(argv[2]) : 200, LANES = argc > 3 ? atoi(argv[3]) : 64;
 	g_single = argc > 4 && !strcmp(argv[4], "single");
-	const int ckpt = argc > 5 && !strcmp(argv[4], "ckpt") ? atoi(argv[5]) : 0; // ./wave_emul <seed> <n> 128 ckpt <rows per chunk>
+	const bool ring96 = argc > 5 && !strcmp(argv[4], "ckpt96"); // ./wave_emul <seed> <n> 96 ckpt96 <rows per chunk>
+	const int ckpt = argc > 5 && (!strcmp(argv[4], "ckpt") || ring96) ? atoi(argv[5]) : 0; // ./wave_emul <seed> <n> 128 ckpt <rows per chunk>
 	std::mt19937 g(seed);
 	const int presets[3][6] = {{2, 8, 12, 2, 24, 1}, {1, 4, 6, 2, 26, 1}, {2, 4, 4, 2, 24, 1}};
 	int n_run = 0, n_bad = 0, n_skip = 0;
@@ -323,6 +434,7 @@ int main(int argc, char **argv)
 		else if (LANES == 10) tlen = (it % 4 == 0) ? 150 : 100 + g() % 61, w = (it % 4 == 0) ? 150 : 32 + g() % 130; // targets of <= 160 bases
 		else if (LANES == 8) tlen = 30 + g() % 99, w = 20 + g() % 130;                                                // <= 128
 		else if (LANES == 128) tlen = 1500 + g() % 3000, w = (it % 3 == 0) ? 1300 : 1010 + g() % 1000, sub = 0.03, ins = 0.02, del = 0.02; // ONT bands
+		else if (LANES == 96) tlen = 1500 + g() % 3000, w = (it % 3 == 0) ? 1300 : 1010 + g() % 480, sub = 0.03, ins = 0.02, del = 0.02; // ... that fit 96 blocks
 		else {
 			switch (it % 5) {
 			case 0: tlen = 150, w = 150; break;
@@ -359,7 +471,7 @@ int main(int argc, char **argv)
 		// (the extz2 oracle has the SSE score rule only: identical to the AVX-512 table except for query byte 7, which the single runs avoid)
 		if (g_single) gdo_ksw_extz2(qlen, q.data(), tlen, t.data(), 5, mat, P[2], P[3], w, -1, 0, GDO_EZ_APPROX_MAX, &ez);
 		else gdo_ksw_extd2(qlen, q.data(), tlen, t.data(), 5, mat, P[2], P[3], P[4], P[5], w, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez);
-		EmuResult e = ckpt ? emulate_ckpt(q.data(), qlen, t.data(), tlen, w, C, ckpt) : emulate(LANES, q.data(), qlen, t.data(), tlen, w, C);
+		EmuResult e = ckpt ? emulate_ckpt(q.data(), qlen, t.data(), tlen, w, C, ckpt, ring96) : emulate(LANES, q.data(), qlen, t.data(), tlen, w, C);
 		++n_run;
 		bool ok = e.score == ez.score && (int)e.cigar.size() == ez.n_cigar && (ez.n_cigar == 0 || !memcmp(e.cigar.data(), ez.cigar, 4 * ez.n_cigar));
 		if (!ok) {

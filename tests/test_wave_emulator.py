@@ -39,3 +39,12 @@ def test_checkpointed_cone_pass_matches_oracle(emul, seed, n, rows):
     out = subprocess.run([emul, str(seed), str(n), "128", "ckpt", str(rows)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
+
+
+@pytest.mark.parametrize("seed,n,rows", [(4, 60, 960), (7, 40, 320)])
+def test_checkpointed_96_block_ring_matches_oracle(emul, seed, n, rows):
+    """first pass on the 96-block ring (one block + one half block per lane: gdw96_row, half-block core functions, the tracker
+    hand-overs across halves, snapshots assembled from halves in the 128-position record format), second pass = the cone"""
+    out = subprocess.run([emul, str(seed), str(n), "96", "ckpt96", str(rows)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout
