@@ -692,7 +692,7 @@ __device__ __forceinline__ void gdw96_save(const Wave96State &S, u32 *ck_chunk /
 	}
 }
 
-__global__ __launch_bounds__(128) void ksw_extd2_wave96c_kernel(const KswTask *__restrict__ tasks,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void ksw_extd2_wave96c_kernel(const KswTask *__restrict__ tasks,
                                                                 const int32_t *__restrict__ task_ids, int n_tasks,
                                                                 const uint8_t *__restrict__ qseq,
                                                                 const uint8_t *__restrict__ tseq,

@@ -3,8 +3,8 @@
 Not the headline bench (bench.py = configs[3]); same structure, smaller synthetic reference by default.
 
     python tools/bench_variant.py --kind sr  [--batch 262144] [--ref-mbp 400] [--steps 5]
-    python tools/bench_variant.py --kind ont [--batch 9216] [--inflight 3] [--ref-mbp 3088] [--steps 4]
-      (9216 reads per batch = three rounds of the 3072 resident wavefronts of the checkpointed wide-band kernel: the long tail of the
+    python tools/bench_variant.py --kind ont [--batch 12288] [--inflight 3] [--ref-mbp 3088] [--steps 4]
+      (12288 reads per batch = three rounds of the 4096 resident wavefronts of the checkpointed wide-band kernel (96-block ring, 4 per SIMD): the long tail of the
       read-length distribution -- a 150 kbp read runs three times as long as the median one -- is then hidden behind the refill)
 """
 import argparse
@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=1)
     ap.add_argument("--host-threads", type=int, default=0)
     a = ap.parse_args()
-    n = a.batch or (262144 if a.kind == "sr" else 9216)
+    n = a.batch or (262144 if a.kind == "sr" else 12288)
     pkg = _load_pkg()
     ctx = pkg.Context(0)
     names, contigs = bench.synth_reference(a.ref_mbp, seed=2)
