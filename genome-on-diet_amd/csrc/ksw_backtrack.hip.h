@@ -235,7 +235,7 @@ __device__ __forceinline__ void gd_walk_push(GdWalk &W, uint32_t *cg, int cap, i
 }
 // cone_stride > 0: rows of `chunk` hold the 64 blocks [cone_b0, cone_b0 + 63] (gdw_cone_row) instead of the blocks of the band
 __device__ __forceinline__ void gd_walk_rows(GdWalk &W, const KswTask &T, const uint8_t *__restrict__ chunk, int r0, int qlen, int tlen, int w,
-                                             uint32_t *__restrict__ cigar, int lane, int cone_stride = 0, int cone_b0 = 0)
+                                             uint32_t *__restrict__ cigar, int lane, int cone_stride = 0, int cone_b0 = 0, bool cone_half = false)
 {
 	uint32_t *cg = cigar + T.cig_off;
 	const int cap = __builtin_amdgcn_readfirstlane(T.cig_cap);
@@ -253,9 +253,14 @@ __device__ __forceinline__ void gd_walk_rows(GdWalk &W, const KswTask &T, const 
 			if (ik < off) fs = 2;
 			if (ik > off_end) fs = 1;
 			if (fs < 0) {
-				const int c = ik & 15, g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
-				const int b = (ik >> 4) - (cone_stride > 0 ? cone_b0 : off >> 4);
-				pf = chunk[(size_t)(r - r0) * row_bytes + (size_t)(b << 4) + (g << 2) + h];
+				if (cone_half) { // rows of 64 half blocks (gdw_cone_row_half): cone_b0 is a half-block index, byte 4g + h = cell 2g + (h & 1) + 4 (h >> 1)
+					const int c = ik & 7, g = (c & 3) >> 1, h = (c & 1) | ((c >> 2) << 1);
+					pf = chunk[(size_t)(r - r0) * row_bytes + (size_t)(((ik >> 3) - cone_b0) << 3) + (g << 2) + h];
+				} else {
+					const int c = ik & 15, g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
+					const int b = (ik >> 4) - (cone_stride > 0 ? cone_b0 : off >> 4);
+					pf = chunk[(size_t)(r - r0) * row_bytes + (size_t)(b << 4) + (g << 2) + h];
+				}
 			}
 		}
 		for (int k = 0; k < 64; ++k) {

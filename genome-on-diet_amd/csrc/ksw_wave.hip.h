@@ -436,7 +436,7 @@ __global__ __launch_bounds__(128) void ksw_extd2_wave128_kernel(const KswTask *_
 // end: restore the snapshot of the chunk, recompute its rows (the cone of the walk only, below) into a GD_CK_ROWS-row buffer (1 MB), let the walk consume them, go
 // on with the chunk below.  ~1.85x the arithmetic (the first pass drops the flag / direction bytes), 4.9 MB instead of 134 MB per
 // alignment: thousands in flight.  Rows, scores and CIGARs are those of the kernel above (same row function, same walk).
-#define GD_CK_ROWS 960  // <= 62 * 16: the cells a walk can visit inside one chunk, and all they depend on, span at most 64 blocks (gdw_cone_row)
+#define GD_CK_ROWS 480  // the cells a walk can visit inside one chunk, and all they depend on, span at most 62 HALF blocks (gdw_cone_row_half; <= 31 blocks for gdw_cone_row)
 #define GD_CK_REGS 136 // dwords per lane per snapshot: 2 x (48 state + 16 Sb/Tb/Qc/SEL + tn, blk, R) + Rf + pad
 static inline __host__ __device__ size_t gd_ck_bytes(int qlen, int tlen, int /*row_bytes*/)
 {
@@ -505,6 +505,53 @@ __device__ __forceinline__ void gdw_cone_row(WaveLane &L, const WaveK &K, bool a
 		u32 out[4];
 		gdw_compute<true>(L, K, W, pX, pV, pX2, out);
 		*reinterpret_cast<uint4 *>(pr + (lane << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+	}
+	prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up;
+}
+
+// the same with one HALF block per lane: a chunk of 480 anti-diagonals has a cone of at most 481 cells = 62 half blocks, so the 64
+// lanes hold the half blocks [hb0, hb0 + 63], hb0 = (i1 >> 3) - 63 -- four packed registers per state array instead of eight, half
+// the instructions of gdw_cone_row again.  Rows of the chunk buffer: 64 x 8 bytes.
+__device__ __forceinline__ void gdw_cone_restore_half(WaveHalf &H, const WaveK &K, const u32 *ck_chunk, int hidx, int r0,
+                                                      const uint8_t *query, int qlen, const uint8_t *target, int tlen)
+{
+	const int blk = hidx >> 1, half = hidx & 1;
+	bool have = false;
+	if (blk >= 0) {
+		const int pos = blk & 127;
+		const u32 *d = ck_chunk + (pos >> 1) + (pos & 1) * 67 * 64;
+		if ((int32_t)d[65 * 64] == blk) {
+			WaveLane L;
+			gdw_lane_load(L, d);
+			gdw_half_from_lane(L, half, H);
+			have = true;
+		}
+	}
+	if (!have) gdw_fresh_half(H, K, blk, half, r0 > 0 ? r0 - 1 : 0, query, qlen, target, tlen);
+}
+
+__device__ __forceinline__ void gdw_cone_row_half(WaveHalf &H, const WaveK &K, bool any_tn, int r, int qlen, int tlen, int w, const uint8_t *query, int hb0, int lane,
+                                                  int &prev_st_, int &prev_st0, int &prev_up, uint8_t *pr)
+{
+	WaveRow W;
+	W.r = r;
+	gdw_band_uniform(r, qlen, tlen, w, W.st0, W.en0);
+	W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+	W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+	const int advanced = W.st_ > prev_st_;
+	W.use_array = advanced;
+	W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open;
+	W.set_tr = (W.en0 | 15) >= r;
+	W.ukey = gdw_edge_key(K, r);
+	const u32 pX = gdw_ror1<64>(H.X[3]), pV = gdw_ror1<64>(H.V[3]), pX2 = gdw_ror1<64>(H.X2[3]), pQ = gdw_ror1<64>(H.Qc[1]);
+	if (r > 0) gdw_shift_query_half(H, pQ, lane == 0, gdw_seam_byte(query, qlen, r - (hb0 << 3)));
+	if (W.set_tr) gdw_reset_tr_half(H, K, W);
+	if (W.st0 != prev_st0 || W.up != prev_up || advanced) gdw_make_sel_half(H, W.st0, W.up);
+	gdw_update_scores_half(H, K, any_tn);
+	if (H.blk >= W.st_ && H.blk <= W.en_) {
+		u32 out[2];
+		gdw_compute_half<true>(H, K, W, pX, pV, pX2, out);
+		*reinterpret_cast<uint2 *>(pr + (lane << 3)) = make_uint2(out[0], out[1]);
 	}
 	prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up;
 }
@@ -735,29 +782,29 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void k
 			status[tid] = GD_ST_TRACED;
 		}
 	}
-	// ---- pass 2: as in ksw_extd2_wave128c_kernel ----
+	// ---- pass 2: the cone of the walk with one half block per lane ----
 	GdWalk Wk;
 	gd_walk_init(Wk, qlen, tlen);
-	WaveLane L;
+	WaveHalf Hc;
 	for (int kk = n_ck - 1; kk >= 0 && Wk.i >= 0 && Wk.j >= 0; --kk) {
 		const int k = __builtin_amdgcn_readfirstlane(kk);
 		const int i1 = __builtin_amdgcn_readfirstlane(Wk.i), rtop = i1 + __builtin_amdgcn_readfirstlane(Wk.j);
 		const int r0 = k * GD_CK_ROWS;
 		if (rtop < r0) continue;
 		const int r1 = rtop < r0 + GD_CK_ROWS - 1 ? rtop : r0 + GD_CK_ROWS - 1;
-		const int b0 = (i1 >> 4) - 63;
+		const int hb0 = (i1 >> 3) - 63;
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-		gdw_cone_restore(L, K, ck + (size_t)k * GD_CK_REGS * 64, b0 + lane, r0, query, qlen, target, tlen);
-		const bool any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0;
+		gdw_cone_restore_half(Hc, K, ck + (size_t)k * GD_CK_REGS * 64, hb0 + lane, r0, query, qlen, target, tlen);
+		const bool any_tn = __builtin_amdgcn_ballot_w64(Hc.tn != 0) != 0;
 		int prev_st_ = 0, prev_st0 = -1, prev_up = -1;
 		if (r0 > 0) {
 			int st0, en0;
 			gdw_band_uniform(r0 - 1, qlen, tlen, w, st0, en0);
 			prev_st_ = st0 >> 4, prev_st0 = st0, prev_up = st0 + (((en0 - st0 + 16) >> 4) << 4);
 		}
-		for (int r = r0; r <= r1; ++r) gdw_cone_row(L, K, any_tn, r, qlen, tlen, w, query, b0, lane, prev_st_, prev_st0, prev_up, chunk + (size_t)(r - r0) * 1024);
+		for (int r = r0; r <= r1; ++r) gdw_cone_row_half(Hc, K, any_tn, r, qlen, tlen, w, query, hb0, lane, prev_st_, prev_st0, prev_up, chunk + (size_t)(r - r0) * 512);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-		gd_walk_rows(Wk, *Tp, chunk, r0, qlen, tlen, w, cigar, lane, 1024, b0);
+		gd_walk_rows(Wk, *Tp, chunk, r0, qlen, tlen, w, cigar, lane, 512, hb0, true);
 	}
 	gd_walk_finish(Wk, *Tp, tid, n_cigar, cigar, lane);
 }

@@ -521,15 +521,18 @@ GDW_HD void gdw_reset_tr_half(WaveHalf &H, const WaveK &K, const WaveRow &W)
 		}
 }
 
-// one anti-diagonal of an ACTIVE half block, state and score only (no backtrace: the first pass of the checkpointed form).
-// pX / pV / pX2: the last packed register of X / V / X2 of the (half) block below, row r-1 values.
-GDW_HD void gdw_compute_half(WaveHalf &H, const WaveK &K, const WaveRow &W, u32 pX, u32 pV, u32 pX2)
+// one anti-diagonal of an ACTIVE half block.  pX / pV / pX2: the last packed register of X / V / X2 of the (half) block below, row r-1
+// values.  BT = false: state and score only (the first pass of the checkpointed form); BT = true: bt[2] receives the half's 8
+// backtrace bytes, coded as in gdw_compute, byte 4g + h = cell 2g + (h & 1) + 4 (h >> 1).
+template <bool BT = false>
+GDW_HD void gdw_compute_half(WaveHalf &H, const WaveK &K, const WaveRow &W, u32 pX, u32 pV, u32 pX2, u32 *bt = nullptr)
 {
 	if (!W.use_array) {
 		const u32 first = (H.blk == W.st_ && H.half == 0) ? ~0u : 0u;
 		pX = gdw_bfi_s(first, K.cx, pX), pV = gdw_bfi_s(first, gdw_pack2(W.v1key), pV), pX2 = gdw_bfi_s(first, K.cx2, pX2);
 	}
 	const u32 inX = gdw_alignbit(H.X[3], pX, 16), inV = gdw_alignbit(H.V[3], pV, 16), inX2 = gdw_alignbit(H.X2[3], pX2, 16);
+	u32 zk_hi = 0;
 #pragma unroll
 	for (int k = 3; k >= 0; --k) {
 		const u32 xin = k ? H.X[k - 1] : inX, vin = k ? H.V[k - 1] : inV, x2in = k ? H.X2[k - 1] : inX2;
@@ -543,7 +546,57 @@ GDW_HD void gdw_compute_half(WaveHalf &H, const WaveK &K, const WaveRow &W, u32 
 		H.X[k] = pk_max(pk_sub(a, tE), K.cx), H.Y[k] = pk_max(pk_sub(b, tE), K.cy);
 		H.X2[k] = pk_max(pk_sub(a2, tE2), K.cx2), H.Y2[k] = pk_max(pk_sub(b2, tE2), K.cy2);
 		H.U[k] = nU, H.V[k] = nV;
+		if (BT) {
+			if (k & 1) zk_hi = zk;
+			else {
+				const u32 mX = gdw_perm(H.X[k + 1], H.X[k], 0x0b090a08u), mY = gdw_perm(H.Y[k + 1], H.Y[k], 0x0b090a08u);
+				const u32 mX2 = gdw_perm(H.X2[k + 1], H.X2[k], 0x0b090a08u), mY2 = gdw_perm(H.Y2[k + 1], H.Y2[k], 0x0b090a08u);
+				const u32 f = gdw_bfi_u(0x80808080u, mX, gdw_bfi_u(0x40404040u, mY, gdw_bfi_u(0x20202020u, mX2, mY2)));
+				bt[k >> 1] = gdw_bfi_u(0xf0f0f0f0u, f, gdw_perm(zk_hi, zk, 0x06020400u));
+			}
+		}
 	}
+}
+
+// a half block out of a block's full record (register k = cells (k, k+8)): cells 8h + j and 8h + j + 4 are the 16-bit halves h of
+// registers j and j + 4
+GDW_HD u32 gdw_half_pick(u32 rj, u32 rj4, int h) { return h ? (rj >> 16) | (rj4 & 0xffff0000u) : (rj & 0xffffu) | (rj4 << 16); }
+GDW_HD void gdw_half_from_lane(const WaveLane &L, int h, WaveHalf &H)
+{
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		H.U[j] = gdw_half_pick(L.U[j], L.U[j + 4], h), H.V[j] = gdw_half_pick(L.V[j], L.V[j + 4], h);
+		H.X[j] = gdw_half_pick(L.X[j], L.X[j + 4], h), H.Y[j] = gdw_half_pick(L.Y[j], L.Y[j + 4], h);
+		H.X2[j] = gdw_half_pick(L.X2[j], L.X2[j + 4], h), H.Y2[j] = gdw_half_pick(L.Y2[j], L.Y2[j + 4], h);
+	}
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		H.Sb[g] = h ? L.Sb[2 + g] : L.Sb[g], H.Tb[g] = h ? L.Tb[2 + g] : L.Tb[g];
+		H.Qc[g] = h ? L.Qc[2 + g] : L.Qc[g], H.SEL[g] = h ? L.SEL[2 + g] : L.SEL[g];
+	}
+	H.tn = (H.Tb[0] | H.Tb[1]) & 0x04040404u;
+	H.blk = L.blk, H.half = h, H.R = 0;
+}
+// the pristine half block of any index (also below block 0 or beyond the target), its query bytes those of anti-diagonal rq
+GDW_HD void gdw_fresh_half(WaveHalf &H, const WaveK &K, int blk, int half, int rq, const uint8_t *query, int qlen, const uint8_t *target, int tlen)
+{
+	const int tb = blk * 16 + half * 8;
+	H.blk = blk, H.half = half;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) H.U[k] = K.uv0, H.V[k] = K.uv0, H.X[k] = K.cx, H.Y[k] = K.cy, H.X2[k] = K.cx2, H.Y2[k] = K.cy2;
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		u32 tw = 0, qw = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int t = tb + 4 * g + b;
+			tw |= (t >= 0 && t < tlen ? (u32)target[t] : 0u) << (8 * b);
+			qw |= gdw_qbyte(query, qlen, rq - t) << (8 * b);
+		}
+		H.Tb[g] = tw, H.Qc[g] = qw, H.Sb[g] = K.s0, H.SEL[g] = 0x03020100u;
+	}
+	H.tn = (H.Tb[0] | H.Tb[1]) & 0x04040404u;
+	H.R = 0;
 }
 
 GDW_HD int gdw_sum8(const u32 A[4])

@@ -320,7 +320,78 @@ static EmuResult emulate_ckpt(const uint8_t *query, int qlen, const uint8_t *tar
 		if (!cg.empty() && (cg.back() & 0xf) == op) cg.back() += len << 4;
 		else cg.push_back(len << 4 | op);
 	};
-	for (int k = (int)snap.size() - 1; k >= 0 && wi >= 0 && wj >= 0; --k) {
+	for (int k = (int)snap.size() - 1; k >= 0 && wi >= 0 && wj >= 0 && ring96; --k) { // the cone with one HALF block per lane (gdw_cone_restore_half / gdw_cone_row_half)
+		const int r0 = k * CK, rtop = wi + wj;
+		if (rtop < r0) continue;
+		const int r1 = rtop < r0 + CK - 1 ? rtop : r0 + CK - 1, hb0 = (wi >> 3) - 63;
+		std::vector<WaveHalf> Cn(64);
+		for (int l = 0; l < 64; ++l) {
+			const int hidx = hb0 + l, blk = hidx >> 1, half = hidx & 1;
+			bool have = false;
+			if (blk >= 0 && snap[k][blk & 127].blk == blk) gdw_half_from_lane(snap[k][blk & 127], half, Cn[l]), have = true;
+			if (!have) gdw_fresh_half(Cn[l], K, blk, half, r0 > 0 ? r0 - 1 : 0, query, qlen, target, tlen);
+		}
+		bool any_tn = false;
+		for (int l = 0; l < 64; ++l) any_tn |= Cn[l].tn != 0;
+		int pst_ = 0, pst0 = -1, pup = -1;
+		if (r0 > 0) {
+			int st0, en0;
+			gd_band(r0 - 1, qlen, tlen, w, st0, en0);
+			pst_ = st0 >> 4, pst0 = st0, pup = st0 + (((en0 - st0 + 16) >> 4) << 4);
+		}
+		std::vector<uint8_t> buf((size_t)(r1 - r0 + 1) * 512, 0xEE), valid((size_t)(r1 - r0 + 1) * 64, 0);
+		for (int r = r0; r <= r1; ++r) {
+			WaveRow W;
+			W.r = r;
+			gd_band(r, qlen, tlen, w, W.st0, W.en0);
+			W.st_ = W.st0 >> 4, W.en_ = W.en0 >> 4;
+			W.up = W.st0 + (((W.en0 - W.st0 + 16) >> 4) << 4);
+			const int advanced = W.st_ > pst_;
+			W.use_array = advanced, W.v1key = W.st_ == 0 ? gdw_edge_key(K, r) : K.key_open, W.set_tr = (W.en0 | 15) >= r, W.ukey = gdw_edge_key(K, r);
+			u32 pX[64], pV[64], pX2[64], pQ[64];
+			for (int l = 0; l < 64; ++l) {
+				const int p = (l + 63) % 64;
+				pX[l] = Cn[p].X[3], pV[l] = Cn[p].V[3], pX2[l] = Cn[p].X2[3], pQ[l] = Cn[p].Qc[1];
+			}
+			for (int l = 0; l < 64; ++l) {
+				if (r > 0) gdw_shift_query_half(Cn[l], pQ[l], l == 0, gdw_qbyte(query, qlen, r - hb0 * 8));
+				if (W.set_tr) gdw_reset_tr_half(Cn[l], K, W);
+				if (W.st0 != pst0 || W.up != pup || advanced) gdw_make_sel_half(Cn[l], W.st0, W.up);
+				gdw_update_scores_half(Cn[l], K, any_tn);
+			}
+			for (int l = 0; l < 64; ++l)
+				if (Cn[l].blk >= W.st_ && Cn[l].blk <= W.en_) {
+					u32 out[2];
+					gdw_compute_half<true>(Cn[l], K, W, pX[l], pV[l], pX2[l], out);
+					memcpy(&buf[(size_t)(r - r0) * 512 + l * 8], out, 8);
+					valid[(size_t)(r - r0) * 64 + l] = 1;
+				}
+			pst_ = W.st_, pst0 = W.st0, pup = W.up;
+		}
+		while (wi >= 0 && wj >= 0 && wi + wj >= r0) {
+			const int r = wi + wj;
+			int st0, en0, force_state = -1;
+			gd_band(r, qlen, tlen, w, st0, en0);
+			const int off = st0 & ~15, off_end = en0 | 15;
+			if (wi < off) force_state = 2;
+			if (wi > off_end) force_state = 1;
+			uint32_t tmp = 0;
+			if (force_state < 0) {
+				const int b = (wi >> 3) - hb0, c = wi & 7, g = (c & 3) >> 1, h = (c & 1) | ((c >> 2) << 1);
+				if (r > r1 || b < 0 || b > 63 || !valid[(size_t)(r - r0) * 64 + b]) { fprintf(stderr, "walk left the half-block cone: r=%d i=%d chunk [%d,%d] hb0=%d\n", r, wi, r0, r1, hb0); exit(2); }
+				const uint8_t bb = buf[(size_t)(r - r0) * 512 + b * 8 + 4 * g + h], nb = (uint8_t)~bb;
+				tmp = (uint8_t)((4 - (bb & 7)) | ((nb >> 4) & 0x08) | ((nb >> 2) & 0x10) | (nb & 0x20) | ((nb << 2) & 0x40));
+			}
+			if (state == 0) state = tmp & 7;
+			else if (!(tmp >> (state + 2) & 1)) state = 0;
+			if (state == 0) state = tmp & 7;
+			if (force_state >= 0) state = force_state;
+			if (state == 0) push(0, 1), --wi, --wj;
+			else if (state == 1 || state == 3) push(2, 1), --wi;
+			else push(1, 1), --wj;
+		}
+	}
+	for (int k = (int)snap.size() - 1; k >= 0 && wi >= 0 && wj >= 0 && !ring96; --k) {
 		const int r0 = k * CK, rtop = wi + wj;
 		if (rtop < r0) continue;
 		const int r1 = rtop < r0 + CK - 1 ? rtop : r0 + CK - 1, b0 = (wi >> 4) - 63;

@@ -245,7 +245,8 @@ def test_error_behaviour_of_the_abi(gpu_ctx, pkg):
 def test_wide_band_kernels_match_oracle(pkg, oracle, monkeypatch, two_waves):
     """ONT bands (w = 1300: more than 64 blocks in flight) on the wide-band kernels -- two blocks per lane in one wavefront,
     two wavefronts per alignment exchanging their boundary through LDS, and the checkpointed form of the first (no stored
-    backtrace: snapshots every 960 anti-diagonals, the cone of the walk recomputed chunk by chunk with one block per lane; alignments of 1 to 10 chunks here) -- against the oracle"""
+    backtrace: snapshots every 480 anti-diagonals, the cone of the walk recomputed chunk by chunk -- one half block per lane behind the
+    96-block-ring first pass, one block per lane for bands wider than 95 blocks; alignments of 1 to 20 chunks here) -- against the oracle"""
     gdo, lib = oracle
     if two_waves == "ckpt":
         monkeypatch.setenv("GDIET_WIDE_CKPT", "1")
@@ -259,7 +260,7 @@ def test_wide_band_kernels_match_oracle(pkg, oracle, monkeypatch, two_waves):
         for i in range(24):
             n = int(rng.integers(1400, 5000))
             if two_waves == "ckpt" and i % 6 == 0:
-                n = [480, 960, 961, 1440][i // 6 % 4]  # rend + 1 around multiples of the chunk size (960 anti-diagonals)
+                n = [240, 480, 481, 720][i // 6 % 4]  # rend + 1 around multiples of the chunk size (480 anti-diagonals)
             q, t = gdo.make_pair(rng, n, 0.03, 0.02, 0.02, n_frac=0.01 if i % 5 == 0 else 0.0)
             if i % 4 == 1:
                 q = q.copy()
@@ -278,7 +279,7 @@ def test_wide_band_kernels_match_oracle(pkg, oracle, monkeypatch, two_waves):
 
 
 def test_checkpointed_kernel_on_a_very_long_alignment(pkg, oracle, monkeypatch):
-    """one 120 kbp x 120 kbp ONT-like pair (w = 1300: 250 chunks of 960 anti-diagonals, 319 MB of backtrace in the reference's layout,
+    """one 120 kbp x 120 kbp ONT-like pair (w = 1300: 500 chunks of 480 anti-diagonals, 319 MB of backtrace in the reference's layout,
     9.6 MB here) through the checkpointed wide-band kernel against the oracle, plus its consistency with the stored-backtrace kernel"""
     gdo, lib = oracle
     rng = np.random.default_rng(77)

@@ -31,7 +31,7 @@ def test_single_affine_form_matches_extz2_oracle(emul, lanes):
     assert "mismatches=0" in out.stdout
 
 
-@pytest.mark.parametrize("seed,n,rows", [(4, 60, 960), (7, 40, 320), (8, 30, 64)])
+@pytest.mark.parametrize("seed,n,rows", [(4, 60, 480), (7, 40, 320), (8, 30, 64)])
 def test_checkpointed_cone_pass_matches_oracle(emul, seed, n, rows):
     """the wide-band kernel without a stored backtrace: pass 1 on the 128-position ring with snapshots every `rows` anti-diagonals,
     pass 2 recomputing only the cone of the walk with one block per lane (gdw_cone_row); a cell the walk reads outside the
@@ -41,10 +41,11 @@ def test_checkpointed_cone_pass_matches_oracle(emul, seed, n, rows):
     assert "mismatches=0" in out.stdout
 
 
-@pytest.mark.parametrize("seed,n,rows", [(4, 60, 960), (7, 40, 320)])
+@pytest.mark.parametrize("seed,n,rows", [(4, 60, 480), (7, 40, 200)])
 def test_checkpointed_96_block_ring_matches_oracle(emul, seed, n, rows):
     """first pass on the 96-block ring (one block + one half block per lane: gdw96_row, half-block core functions, the tracker
-    hand-overs across halves, snapshots assembled from halves in the 128-position record format), second pass = the cone"""
+    hand-overs across halves, snapshots assembled from halves in the 128-position record format), second pass = the cone with one HALF block per lane
+    (gdw_cone_row_half: chunks of at most 496 anti-diagonals)"""
     out = subprocess.run([emul, str(seed), str(n), "96", "ckpt96", str(rows)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
