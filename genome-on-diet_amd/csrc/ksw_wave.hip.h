@@ -195,6 +195,7 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 	// the band limits need no min / max, the selectors are rebuilt only when they change, and what can happen only on one of the two
 	// rows (a block retiring; a block entering the band) is tested only there: -40 scalar and -10 vector instructions per row.
 	const int nblkA = (w - 1 + 16) >> 4, nblkB = (w + 16) >> 4; // blocks whose scores are rewritten on the first / second row of a pair
+	u32 m_lowest = 0; // 0 / ~0: this lane holds the lowest block of the window (of the row just done)
 	auto pair_row = [&](const int r, const int m, auto a_tag) __attribute__((always_inline)) {
 		constexpr bool ROW_A = decltype(a_tag)::value;
 		WaveRow W;
@@ -213,7 +214,7 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 				const u32 sg = gdw_seam_byte(qg[g], qlen, j);
 				seam = row == g ? sg : seam;
 			}
-			gdw_shift_query(L, pQ, L.blk == pst_, seam);
+			gdw_shift_query_m(L, pQ, m_lowest, seam); // (the lane mask of the row before: its st_ is this row's pst_)
 		}
 		if (advanced) {
 			if (L.blk < W.st_) gdw_load_block(L, K, L.blk + LANES, r, query, qlen, target, tlen);
@@ -222,9 +223,9 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 		if (ROW_A || nblkA != nblkB) {
 			u32 lo[4], hi[4];
 			gdw_sel_uniform(m & 15, lo, hi);
-			gdw_pick_sel(L, W.st_, W.up >> 4, (W.up >> 4) - W.st_ >= LANES - 1, lo, hi, W.m_first);
-			W.m_first_valid = 1; // the lane mask "holds the lowest block", for the boundary scalars in gdw_compute
+			gdw_pick_sel(L, W.st_, W.up >> 4, (W.up >> 4) - W.st_ >= LANES - 1, lo, hi, m_lowest);
 		}
+		W.m_first_valid = 1, W.m_first = m_lowest; // the lane mask "holds the lowest block", for the boundary scalars in gdw_compute
 		gdw_update_scores(L, K, any_tn);
 		if (L.blk <= W.en_) {
 			u32 out[4];
@@ -247,6 +248,7 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 		for (; r <= rend && r < rA; ++r) dp_row(r, std::false_type());
 		if (r == rA && rS > rA) {
 			int m = (rA - w + 1) >> 1;
+			m_lowest = L.blk == prev_st_ ? ~0u : 0u;
 			for (; r < rS; r += 2, ++m) {
 				pair_row(r, m, std::true_type());
 				pair_row(r + 1, m, std::false_type());

@@ -489,6 +489,16 @@ GDW_HD void gdw_make_sel_half(WaveHalf &H, int st0, int up)
 	}
 }
 
+// the same with the choice of the lowest block's lane as a 0 / ~0 lane mask (one v_bfi with the scalar seam byte as data)
+GDW_HD void gdw_shift_query_m(WaveLane &L, u32 below, u32 m_lowest, u32 seam)
+{
+	const u32 in = gdw_bfi_s(m_lowest, seam << 24, below);
+	L.Qc[3] = gdw_alignbyte(L.Qc[3], L.Qc[2], 3);
+	L.Qc[2] = gdw_alignbyte(L.Qc[2], L.Qc[1], 3);
+	L.Qc[1] = gdw_alignbyte(L.Qc[1], L.Qc[0], 3);
+	L.Qc[0] = gdw_alignbyte(L.Qc[0], in, 3);
+}
+
 GDW_HD void gdw_shift_query_half(WaveHalf &H, u32 below, bool is_lowest, u32 seam)
 {
 	const u32 in = is_lowest ? (seam << 24) : below;
