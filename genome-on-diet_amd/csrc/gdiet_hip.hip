@@ -232,6 +232,7 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 }
 
 static void gd_pool_free(void *pool); // map_pipeline.hip.h
+template <class F> static void gd_parallel_for(gdiet_ctx *ctx, int n_threads, int n, F f); // map_pipeline.hip.h
 static void gd_join_open_tickets(gdiet_ctx *ctx);
 
 extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
@@ -433,21 +434,35 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	std::vector<int32_t> ids[4];
 	int max_cap = 0;
 	ctx->last_mask = 0;
-	struct { int qlen = -1, tlen = -1, w = 0; int32_t kind = 0, row_bytes = 0; } memo;
+	// kernel + backtrace geometry of every alignment first, on the host threads: the admission test of the wave kernels walks the blocks
+	// of the band (~1 000 steps for a 15 kbp alignment: 4-5 ms for the 9 400 alignments of a HiFi batch on one thread -- time that sat
+	// between the gather kernel and the DP kernel whenever a batch was not ready early).  Slices with a memo each: a short-read
+	// batch repeats a few geometries.
+	{
+		const int n_sl = std::max(1, std::min(64, n / 256));
+		gd_parallel_for(ctx, ctx->lane_threads, n_sl, [&](int sl) {
+			struct { int qlen = -1, tlen = -1, w = 0; int32_t kind = 0, row_bytes = 0; } memo;
+			const int i0 = (int)((int64_t)n * sl / n_sl), i1 = (int)((int64_t)n * (sl + 1) / n_sl);
+			for (int i = i0; i < i1; ++i) {
+				KswTask &T = h_tasks[i];
+				T.qlen = (int)(h_qoff[i + 1] - h_qoff[i]), T.tlen = (int)(h_toff[i + 1] - h_toff[i]), T.w = h_w[i];
+				T.kind = GD_KIND_GENERIC, T.row_bytes = 0;
+				if (T.qlen <= 0 || T.tlen <= 0) continue; // (refused below)
+				if (T.qlen == memo.qlen && T.tlen == memo.tlen && T.w == memo.w) T.kind = memo.kind, T.row_bytes = memo.row_bytes;
+				else {
+					gd_plan_one(ctx->kernel_mode, wave_scoring_ok, T.qlen, T.tlen, T.w, T.kind, T.row_bytes);
+					memo.qlen = T.qlen, memo.tlen = T.tlen, memo.w = T.w, memo.kind = T.kind, memo.row_bytes = T.row_bytes;
+				}
+			}
+		});
+	}
 	for (int i = 0; i < n; ++i) {
 		KswTask &T = h_tasks[i];
 		T.qoff = h_qoff[i], T.toff = h_toff[i];
-		T.qlen = (int)(h_qoff[i + 1] - h_qoff[i]), T.tlen = (int)(h_toff[i + 1] - h_toff[i]);
-		T.w = h_w[i];
 		T.cig_off = h_cig[i], T.cig_cap = (int32_t)std::min<int64_t>(h_cig[i + 1] - h_cig[i], 0x7fffffff);
 		T.exact_score = d_exact_score ? h_ex[i] : GD_NEG_INF;
 		T.pad = 0;
 		if (T.qlen <= 0 || T.tlen <= 0) { ctx->err = "empty sequence in batch (the reference returns without aligning)"; return GDIET_E_PARAM; }
-		if (T.qlen == memo.qlen && T.tlen == memo.tlen && T.w == memo.w) T.kind = memo.kind, T.row_bytes = memo.row_bytes;
-		else { // (the admission test of the wave kernels walks the blocks of the band; short-read batches repeat a few geometries)
-			gd_plan_one(ctx->kernel_mode, wave_scoring_ok, T.qlen, T.tlen, T.w, T.kind, T.row_bytes);
-			memo.qlen = T.qlen, memo.tlen = T.tlen, memo.w = T.w, memo.kind = T.kind, memo.row_bytes = T.row_bytes;
-		}
 		if (ctx->kernel_mode == 2 && T.kind == GD_KIND_GENERIC) { ctx->err = "alignment does not fit the wave kernel"; return GDIET_E_PARAM; }
 		if (T.kind == GD_KIND_GENERIC) {
 			int cap = gd_generic_cap(T.qlen, T.tlen, T.w);
