@@ -371,6 +371,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// GDIET_TRACE_STAGES=1: wall time of the host-side sub-steps of this call to stderr (development aid)
 	static const bool trace = getenv("GDIET_TRACE_STAGES") != nullptr;
 	double tr_t = trace ? gd_now() : 0;
+	const double tr_t0 = tr_t;
 	std::string tr_s;
 	auto mark = [&](const char *what) {
 		if (!trace) return;
@@ -686,7 +687,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	if (no_mem.load()) { gdiet_hip_free_regs(n, n_regs, regs); ctx->err = "out of host memory for the records"; return GDIET_E_NOMEM; }
 	ctx->stage_s[4] += gd_now() - t0;
 	mark("post");
-	if (trace) fprintf(stderr, "[gdiet stages, ms] n=%d%s\n", n, tr_s.c_str());
+	if (trace) fprintf(stderr, "[gdiet stages, ms] lane=%p start=%.2f end=%.2f n=%d%s\n", (void *)ctx, 1e3 * fmod(tr_t0, 1000.0), 1e3 * fmod(gd_now(), 1000.0), n, tr_s.c_str());
 	return GDIET_OK;
 }
 
