@@ -32,6 +32,7 @@ struct gdiet_read_batch {
 #include "map_index_dev.hip.h"
 
 #include "host_pool.h"
+#include "nt4_encode.h"
 
 static void gd_pool_free(void *pool) { delete (GdPool *)pool; }
 
@@ -224,8 +225,7 @@ extern "C" int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **out, in
 	if (b->enc.size() < enc_len) b->enc.resize(enc_len + (enc_len >> 3));
 	t_[1] = gd_now();
 	gd_parallel_for(ctx, ctx->host_threads, n, [&](int i) {
-		uint8_t *d = b->enc.data() + b->roff[i];
-		for (int j = 0; j < lens[i]; ++j) d[j] = gd_nt4((unsigned char)seqs[i][j]);
+		if (lens[i] > 0) gd_nt4_encode(seqs[i], b->enc.data() + b->roff[i], (size_t)lens[i]);
 	});
 	t_[2] = gd_now();
 	// stream-ordered allocation: a plain hipMalloc / hipFree per mini-batch synchronises the whole device, i.e. every batch in flight
