@@ -452,7 +452,7 @@ __device__ __forceinline__ void gdw_lane_save(const WaveLane &L, u32 *d) // d: t
 	for (int k = 0; k < 8; ++k) d[(k) * 64] = L.U[k], d[(8 + k) * 64] = L.V[k], d[(16 + k) * 64] = L.X[k], d[(24 + k) * 64] = L.Y[k], d[(32 + k) * 64] = L.X2[k], d[(40 + k) * 64] = L.Y2[k];
 #pragma unroll
 	for (int g = 0; g < 4; ++g) d[(48 + g) * 64] = L.Sb[g], d[(52 + g) * 64] = L.Tb[g], d[(56 + g) * 64] = L.Qc[g], d[(60 + g) * 64] = L.SEL[g];
-	d[64 * 64] = L.tn, d[65 * 64] = (u32)L.blk, d[66 * 64] = (u32)L.R;
+	d[64 * 64] = (L.Tb[0] | L.Tb[1] | L.Tb[2] | L.Tb[3]) & 0x04040404u /* = L.tn */, d[65 * 64] = (u32)L.blk, d[66 * 64] = (u32)L.R;
 }
 __device__ __forceinline__ void gdw_lane_load(WaveLane &L, const u32 *d)
 {
@@ -670,7 +670,7 @@ __device__ __forceinline__ void gdw96_row(Wave96State &S, const WaveK &K, int r,
 	if (advanced) {
 		if (F.blk < W.st_) gdw_load_block(F, K, F.blk + NBLK, r, query, qlen, target, tlen);
 		if (H.blk < W.st_) gdw_load_half(H, K, H.blk + NBLK, H.half, r, query, qlen, target, tlen);
-		S.any_tn = __builtin_amdgcn_ballot_w64((F.tn | H.tn) != 0) != 0;
+		S.any_tn = __builtin_amdgcn_ballot_w64(((F.Tb[0] | F.Tb[1] | F.Tb[2] | F.Tb[3] | H.Tb[0] | H.Tb[1]) & 0x04040404u) != 0) != 0; // (from the bytes: no tn registers in this pass)
 	}
 	// (3) scalar fix-ups and the score row
 	if (W.set_tr) gdw_reset_tr(F, K, W), gdw_reset_tr_half(H, K, W);
@@ -706,6 +706,82 @@ __device__ __forceinline__ void gdw96_row(Wave96State &S, const WaveK &K, int r,
 		S.have_f = 1;
 	}
 	S.prev_st_ = W.st_, S.prev_st0 = W.st0, S.prev_up = W.up, S.prev_en0 = W.en0;
+}
+
+// Rows [rA, rS) of a long alignment (gdw_steady_rows) as pairs, as in ksw_extd2_wave_kernel: on the first row of a pair st0 has just
+// moved up by one cell, on the second en0 has; both follow from m = (r - w + 1) >> 1 without min / max, neither the first block, the
+// cell t == r nor the last target column is involved, a block can retire only on the first row and enter the band only on the
+// second.  m_lowF / m_lowH: 0 / ~0 lane masks "holds the lowest block (its first half)" of the row just done.
+template <bool ROW_A>
+__device__ __forceinline__ void gdw96_pair_row(Wave96State &S, const WaveK &K, int r, int m, int w, int nblkA, int nblkB, const uint8_t *query, int qlen,
+                                               const uint8_t *target, int tlen, int lane, u32 &m_lowF, u32 &m_lowH, u32 *lds /* this lane's 12 dwords: Tb, SEL of F and H */)
+{
+	constexpr int NBLK = 96;
+	WaveLane &F = S.F;
+	WaveHalf &H = S.H;
+	WaveRow W;
+	W.r = r, W.st0 = m, W.en0 = ROW_A ? m + w - 1 : m + w;
+	W.st_ = m >> 4, W.en_ = W.en0 >> 4;
+	W.up = m + ((ROW_A ? nblkA : nblkB) << 4);
+	const int advanced = ROW_A && (m & 15) == 0;
+	const int pst_ = W.st_ - advanced; // st_ of the row before
+	W.use_array = advanced, W.v1key = K.key_open, W.set_tr = 0, W.ukey = 0;
+	const bool l0 = lane == 0;
+	const u32 aX = gdw_ror1<64>(F.X[7]), aV = gdw_ror1<64>(F.V[7]), aX2 = gdw_ror1<64>(F.X2[7]), aQ = gdw_ror1<64>(F.Qc[3]);
+	const u32 bX = gdw_ror1<64>(H.X[3]), bV = gdw_ror1<64>(H.V[3]), bX2 = gdw_ror1<64>(H.X2[3]), bQ = gdw_ror1<64>(H.Qc[1]);
+	const u32 fX = l0 ? bX : aX, fV = l0 ? bV : aV, fX2 = l0 ? bX2 : aX2, fQ = l0 ? bQ : aQ;
+	const u32 hX = l0 ? aX : bX, hV = l0 ? aV : bV, hX2 = l0 ? aX2 : bX2, hQ = l0 ? aQ : bQ;
+	// the target bytes and the score selectors of the lane live in LDS between the rows (read once per row, rewritten every 16 / 2
+	// rows): twelve registers the row loop needs for the pair form's lane masks and its temporaries (the kernel sits at the 128-register limit)
+	{
+		const uint4 t4 = *reinterpret_cast<const uint4 *>(lds), s4 = *reinterpret_cast<const uint4 *>(lds + 4), h4 = *reinterpret_cast<const uint4 *>(lds + 8);
+		F.Tb[0] = t4.x, F.Tb[1] = t4.y, F.Tb[2] = t4.z, F.Tb[3] = t4.w;
+		F.SEL[0] = s4.x, F.SEL[1] = s4.y, F.SEL[2] = s4.z, F.SEL[3] = s4.w;
+		H.Tb[0] = h4.x, H.Tb[1] = h4.y, H.SEL[0] = h4.z, H.SEL[1] = h4.w;
+	}
+	{
+		const u32 seam = gdw_seam_byte(query, qlen, r - (pst_ << 4));
+		gdw_shift_query_m(F, fQ, m_lowF, seam); // (the lane masks of the row before: its st_ is this row's pst_)
+		gdw_shift_query_half_m(H, hQ, m_lowH, seam);
+	}
+	bool dirty = false;
+	if (advanced) {
+		if (F.blk < W.st_) gdw_load_block(F, K, F.blk + NBLK, r, query, qlen, target, tlen);
+		if (H.blk < W.st_) gdw_load_half(H, K, H.blk + NBLK, H.half, r, query, qlen, target, tlen);
+		S.any_tn = __builtin_amdgcn_ballot_w64(((F.Tb[0] | F.Tb[1] | F.Tb[2] | F.Tb[3] | H.Tb[0] | H.Tb[1]) & 0x04040404u) != 0) != 0;
+		dirty = true;
+	}
+	if (ROW_A || nblkA != nblkB) {
+		u32 lo[4], hi[4];
+		gdw_sel_uniform(m & 15, lo, hi);
+		gdw_pick_sel(F, W.st_, W.up >> 4, (W.up >> 4) - W.st_ >= NBLK - 1, lo, hi, m_lowF);
+		gdw_make_sel_half(H, W.st0, W.up);
+		m_lowH = (H.blk == W.st_ && H.half == 0) ? ~0u : 0u;
+		dirty = true;
+	}
+	if (dirty) {
+		*reinterpret_cast<uint4 *>(lds) = make_uint4(F.Tb[0], F.Tb[1], F.Tb[2], F.Tb[3]);
+		*reinterpret_cast<uint4 *>(lds + 4) = make_uint4(F.SEL[0], F.SEL[1], F.SEL[2], F.SEL[3]);
+		*reinterpret_cast<uint4 *>(lds + 8) = make_uint4(H.Tb[0], H.Tb[1], H.SEL[0], H.SEL[1]);
+	}
+	W.m_first_valid = 1, W.m_first = m_lowF, W.m_first_h = m_lowH;
+	gdw_update_scores(F, K, S.any_tn);
+	gdw_update_scores_half(H, K, S.any_tn);
+	if (F.blk <= W.en_) {
+		u32 out[4];
+		gdw_compute(F, K, W, fX, fV, fX2, out);
+	}
+	if (H.blk <= W.en_) gdw_compute_half(H, K, W, hX, hV, hX2);
+	F.R += gdw_lo(F.V[0]), H.R += gdw_lo(H.V[0]); // (the bias B1 of every V key is taken off once, after the loop)
+	if (!ROW_A && (W.en0 & 7) == 0) { // a block, or the second half of one, enters the band
+		const int ha = (int)gdw_ror1<64>((u32)gdw_track_handoff(F)), hb = (int)gdw_ror1<64>((u32)gdw_track_handoff_half(H));
+		const int hf = l0 ? hb : ha, hh = l0 ? ha : hb;
+		if ((W.en0 & 15) == 0) {
+			if (F.blk == W.en_) F.R = hf + gdw_lo(F.U[0]);
+			if (H.blk == W.en_ && H.half == 0) H.R = hh + gdw_lo(H.U[0]);
+		} else if (H.blk == W.en_ && H.half == 1) H.R = hh + gdw_lo(H.U[0]);
+	}
+	S.prev_st_ = W.st_; // (a snapshot may follow)
 }
 
 // a snapshot in the record format gdw_cone_restore reads: the record of ring position p = blk mod 128 sits at column p >> 1, field
@@ -769,14 +845,53 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void k
 		Wave96State S;
 		gdw_load_block(S.F, K, lane, 0, query, qlen, target, tlen);
 		gdw_load_half(S.H, K, 64 + (lane >> 1), lane & 1, 0, query, qlen, target, tlen);
-		S.any_tn = __builtin_amdgcn_ballot_w64((S.F.tn | S.H.tn) != 0) != 0;
+		S.any_tn = __builtin_amdgcn_ballot_w64(((S.F.Tb[0] | S.F.Tb[1] | S.F.Tb[2] | S.F.Tb[3] | S.H.Tb[0] | S.H.Tb[1]) & 0x04040404u) != 0) != 0;
 		S.prev_st_ = 0, S.prev_st0 = -1, S.prev_up = -1, S.prev_en0 = -1, S.have_f = 0, S.Rf = 0;
 		int ck_row = 0, ck_idx = 0;
-		for (int r = 0; r <= rend; ++r) {
+		__shared__ u32 lds_all[2 * 64 * 12]; // (two wavefronts per workgroup)
+		u32 *lds = lds_all + ((threadIdx.x >> 6) * 64 + lane) * 12;
+		auto to_lds = [&]() __attribute__((always_inline)) {
+			*reinterpret_cast<uint4 *>(lds) = make_uint4(S.F.Tb[0], S.F.Tb[1], S.F.Tb[2], S.F.Tb[3]);
+			*reinterpret_cast<uint4 *>(lds + 4) = make_uint4(S.F.SEL[0], S.F.SEL[1], S.F.SEL[2], S.F.SEL[3]);
+			*reinterpret_cast<uint4 *>(lds + 8) = make_uint4(S.H.Tb[0], S.H.Tb[1], S.H.SEL[0], S.H.SEL[1]);
+		};
+		auto from_lds = [&]() __attribute__((always_inline)) {
+			const uint4 t4 = *reinterpret_cast<const uint4 *>(lds), s4 = *reinterpret_cast<const uint4 *>(lds + 4), h4 = *reinterpret_cast<const uint4 *>(lds + 8);
+			S.F.Tb[0] = t4.x, S.F.Tb[1] = t4.y, S.F.Tb[2] = t4.z, S.F.Tb[3] = t4.w;
+			S.F.SEL[0] = s4.x, S.F.SEL[1] = s4.y, S.F.SEL[2] = s4.z, S.F.SEL[3] = s4.w;
+			S.H.Tb[0] = h4.x, S.H.Tb[1] = h4.y, S.H.SEL[0] = h4.z, S.H.SEL[1] = h4.w;
+		};
+		auto snapshot = [&](const int r) __attribute__((always_inline)) {
 			if (r == ck_row) {
 				gdw96_save(S, ck + (size_t)ck_idx * GD_CK_REGS * 64, lane);
 				ck_row += GD_CK_ROWS, ++ck_idx;
 			}
+		};
+		int rA, rS, r = 0;
+		gdw_steady_rows(qlen, tlen, w, rA, rS);
+		for (; r <= rend && r < rA; ++r) {
+			snapshot(r);
+			gdw96_row(S, K, r, qlen, tlen, w, query, target, lane, mlast, sl);
+		}
+		if (r == rA && rS > rA) { // the rows in the middle, as pairs
+			const int nblkA = (w - 1 + 16) >> 4, nblkB = (w + 16) >> 4;
+			int m = (rA - w + 1) >> 1;
+			u32 m_lowF = S.F.blk == S.prev_st_ ? ~0u : 0u, m_lowH = (S.H.blk == S.prev_st_ && S.H.half == 0) ? ~0u : 0u;
+			to_lds();
+			for (; r < rS; r += 2, ++m) {
+				if (r == ck_row || r + 1 == ck_row) from_lds(); // (a snapshot stores the whole lane)
+				snapshot(r);
+				gdw96_pair_row<true>(S, K, r, m, w, nblkA, nblkB, query, qlen, target, tlen, lane, m_lowF, m_lowH, lds);
+				snapshot(r + 1);
+				gdw96_pair_row<false>(S, K, r + 1, m, w, nblkA, nblkB, query, qlen, target, tlen, lane, m_lowF, m_lowH, lds);
+			}
+			from_lds();
+			S.F.R -= (rS - rA) * K.B1, S.H.R -= (rS - rA) * K.B1; // the trackers of the paired rows accumulated the V keys with their bias
+			--m; // the band of the last row, for the rows that follow
+			S.prev_st_ = m >> 4, S.prev_st0 = m, S.prev_up = m + (nblkB << 4), S.prev_en0 = m + w;
+		}
+		for (; r <= rend; ++r) {
+			snapshot(r);
 			gdw96_row(S, K, r, qlen, tlen, w, query, target, lane, mlast, sl);
 		}
 		if (S.F.blk == mlast || (S.H.blk == mlast && S.H.half == (sl >> 3))) {

@@ -214,7 +214,7 @@ struct WaveRow {
 	int set_tr;      // en >= r: cell t == r gets u/y/y2 reset (:160-163)
 	int ukey;        // key of u[r] for that reset
 	int m_first_valid = 0; // the caller already holds the lane mask "this lane's block is st_" (paired rows)
-	u32 m_first = 0;
+	u32 m_first = 0, m_first_h = 0; // (m_first_h: the same for a half block -- "the first half of block st_")
 };
 
 // selectors for the score blend of one lane: cells [st0, up) are rewritten (:166-180)
@@ -506,6 +506,13 @@ GDW_HD void gdw_shift_query_half(WaveHalf &H, u32 below, bool is_lowest, u32 sea
 	H.Qc[0] = gdw_alignbyte(H.Qc[0], in, 3);
 }
 
+GDW_HD void gdw_shift_query_half_m(WaveHalf &H, u32 below, u32 m_lowest, u32 seam) // (the lowest half's lane as a 0 / ~0 mask)
+{
+	const u32 in = gdw_bfi_s(m_lowest, seam << 24, below);
+	H.Qc[1] = gdw_alignbyte(H.Qc[1], H.Qc[0], 3);
+	H.Qc[0] = gdw_alignbyte(H.Qc[0], in, 3);
+}
+
 GDW_HD void gdw_update_scores_half(WaveHalf &H, const WaveK &K, bool any_tn)
 {
 #pragma unroll
@@ -538,7 +545,7 @@ template <bool BT = false>
 GDW_HD void gdw_compute_half(WaveHalf &H, const WaveK &K, const WaveRow &W, u32 pX, u32 pV, u32 pX2, u32 *bt = nullptr)
 {
 	if (!W.use_array) {
-		const u32 first = (H.blk == W.st_ && H.half == 0) ? ~0u : 0u;
+		const u32 first = W.m_first_valid ? W.m_first_h : ((H.blk == W.st_ && H.half == 0) ? ~0u : 0u);
 		pX = gdw_bfi_s(first, K.cx, pX), pV = gdw_bfi_s(first, gdw_pack2(W.v1key), pV), pX2 = gdw_bfi_s(first, K.cx2, pX2);
 	}
 	const u32 inX = gdw_alignbit(H.X[3], pX, 16), inV = gdw_alignbit(H.V[3], pV, 16), inX2 = gdw_alignbit(H.X2[3], pX2, 16);

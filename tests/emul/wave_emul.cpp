@@ -156,7 +156,7 @@ static int pass1_ring96(const uint8_t *query, int qlen, const uint8_t *target, i
 	std::vector<WaveHalf> H(64);
 	for (int l = 0; l < 64; ++l) gdw_load_block(F[l], K, l, 0, query, qlen, target, tlen), gdw_load_half(H[l], K, 64 + (l >> 1), l & 1, 0, query, qlen, target, tlen);
 	int prev_st_ = 0, prev_st0 = -1, prev_up = -1, prev_en0 = -1, have_f = 0, Rf = 0;
-	for (int r = 0; r <= rend; ++r) {
+	auto snapshot = [&](const int r) {
 		if (r % CK == 0) { // gdw96_save
 			std::vector<WaveLane> rec(128);
 			for (auto &x : rec) memset(&x, 0xEE, sizeof(x)); // (records nobody writes hold whatever was there)
@@ -178,6 +178,8 @@ static int pass1_ring96(const uint8_t *query, int qlen, const uint8_t *target, i
 			for (int l = 0; l < 32; ++l) rec[(prev_st_ + 96 + l) & 127].blk = -1;
 			snap.push_back(rec);
 		}
+	};
+	auto generic_row = [&](const int r) { // gdw96_row
 		WaveRow W;
 		W.r = r;
 		gd_band(r, qlen, tlen, w, W.st0, W.en0);
@@ -249,7 +251,93 @@ static int pass1_ring96(const uint8_t *query, int qlen, const uint8_t *target, i
 			have_f = 1;
 		}
 		prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up, prev_en0 = W.en0;
+	};
+	// gdw96_pair_row: the rows in the middle of a long alignment as pairs (lane masks m_lowF / m_lowH per lane)
+	std::vector<u32> m_lowF(64), m_lowH(64);
+	const int nblkA = (w - 1 + 16) >> 4, nblkB = (w + 16) >> 4;
+	auto pair_row = [&](const int r, const int m, const bool ROW_A) {
+		WaveRow W;
+		W.r = r, W.st0 = m, W.en0 = ROW_A ? m + w - 1 : m + w;
+		W.st_ = m >> 4, W.en_ = W.en0 >> 4;
+		W.up = m + ((ROW_A ? nblkA : nblkB) << 4);
+		{ // the closed forms must be the band of the reference
+			int st0, en0;
+			gd_band(r, qlen, tlen, w, st0, en0);
+			if (st0 != W.st0 || en0 != W.en0 || W.up != st0 + (((en0 - st0 + 16) >> 4) << 4) || (en0 | 15) >= r || st0 < 16 || en0 >= tlen - 1) { fprintf(stderr, "ring96 pair row %d: band mismatch\n", r); exit(2); }
+		}
+		const int advanced = ROW_A && (m & 15) == 0;
+		const int pst_ = W.st_ - advanced;
+		if (pst_ != prev_st_) { fprintf(stderr, "ring96 pair row %d: pst_ %d != prev_st_ %d\n", r, pst_, prev_st_); exit(2); }
+		W.use_array = advanced, W.v1key = K.key_open, W.set_tr = 0, W.ukey = 0;
+		u32 fX[64], fV[64], fX2[64], fQ[64], hX[64], hV[64], hX2[64], hQ[64];
+		for (int l = 0; l < 64; ++l) {
+			const int p = (l + 63) % 64;
+			const u32 aX = F[p].X[7], aV = F[p].V[7], aX2 = F[p].X2[7], aQ = F[p].Qc[3], bX = H[p].X[3], bV = H[p].V[3], bX2 = H[p].X2[3], bQ = H[p].Qc[1];
+			const bool l0 = l == 0;
+			fX[l] = l0 ? bX : aX, fV[l] = l0 ? bV : aV, fX2[l] = l0 ? bX2 : aX2, fQ[l] = l0 ? bQ : aQ;
+			hX[l] = l0 ? aX : bX, hV[l] = l0 ? aV : bV, hX2[l] = l0 ? aX2 : bX2, hQ[l] = l0 ? aQ : bQ;
+		}
+		const u32 seam = gdw_qbyte(query, qlen, r - (pst_ << 4));
+		for (int l = 0; l < 64; ++l) {
+			gdw_shift_query_m(F[l], fQ[l], m_lowF[l], seam);
+			gdw_shift_query_half_m(H[l], hQ[l], m_lowH[l], seam);
+			if (advanced) {
+				if (F[l].blk < W.st_) gdw_load_block(F[l], K, F[l].blk + 96, r, query, qlen, target, tlen);
+				if (H[l].blk < W.st_) gdw_load_half(H[l], K, H[l].blk + 96, H[l].half, r, query, qlen, target, tlen);
+			} else if (F[l].blk < W.st_ || H[l].blk < W.st_) { fprintf(stderr, "ring96 pair row %d: a block below the window\n", r); exit(2); }
+		}
+		bool any_tn = false;
+		for (int l = 0; l < 64; ++l) any_tn |= (F[l].tn | H[l].tn) != 0;
+		if (ROW_A || nblkA != nblkB) {
+			u32 lo[4], hi[4];
+			gdw_sel_uniform(m & 15, lo, hi);
+			for (int l = 0; l < 64; ++l) {
+				gdw_pick_sel(F[l], W.st_, W.up >> 4, (W.up >> 4) - W.st_ >= 96 - 1, lo, hi, m_lowF[l]);
+				gdw_make_sel_half(H[l], W.st0, W.up);
+				m_lowH[l] = (H[l].blk == W.st_ && H[l].half == 0) ? ~0u : 0u;
+			}
+		}
+		for (int l = 0; l < 64; ++l) {
+			gdw_update_scores(F[l], K, any_tn);
+			gdw_update_scores_half(H[l], K, any_tn);
+		}
+		for (int l = 0; l < 64; ++l) {
+			W.m_first_valid = 1, W.m_first = m_lowF[l], W.m_first_h = m_lowH[l];
+			if (F[l].blk <= W.en_) {
+				u32 out[4];
+				gdw_compute<true>(F[l], K, W, fX[l], fV[l], fX2[l], out);
+			}
+			if (H[l].blk <= W.en_) gdw_compute_half(H[l], K, W, hX[l], hV[l], hX2[l]);
+		}
+		for (int l = 0; l < 64; ++l) F[l].R += gdw_lo(F[l].V[0]), H[l].R += gdw_lo(H[l].V[0]);
+		if (!ROW_A && (W.en0 & 7) == 0) {
+			int ha[64], hb[64];
+			for (int l = 0; l < 64; ++l) ha[l] = gdw_track_handoff(F[(l + 63) % 64]), hb[l] = gdw_track_handoff_half(H[(l + 63) % 64]);
+			for (int l = 0; l < 64; ++l) {
+				const int hf = l == 0 ? hb[l] : ha[l], hh = l == 0 ? ha[l] : hb[l];
+				if ((W.en0 & 15) == 0) {
+					if (F[l].blk == W.en_) F[l].R = hf + gdw_lo(F[l].U[0]);
+					if (H[l].blk == W.en_ && H[l].half == 0) H[l].R = hh + gdw_lo(H[l].U[0]);
+				} else if (H[l].blk == W.en_ && H[l].half == 1) H[l].R = hh + gdw_lo(H[l].U[0]);
+			}
+		}
+		prev_st_ = W.st_;
+	};
+	int rA, rS, r = 0;
+	gdw_steady_rows(qlen, tlen, w, rA, rS);
+	for (; r <= rend && r < rA; ++r) snapshot(r), generic_row(r);
+	if (r == rA && rS > rA) {
+		int m = (rA - w + 1) >> 1;
+		for (int l = 0; l < 64; ++l) m_lowF[l] = F[l].blk == prev_st_ ? ~0u : 0u, m_lowH[l] = (H[l].blk == prev_st_ && H[l].half == 0) ? ~0u : 0u;
+		for (; r < rS; r += 2, ++m) {
+			snapshot(r), pair_row(r, m, true);
+			snapshot(r + 1), pair_row(r + 1, m, false);
+		}
+		for (int l = 0; l < 64; ++l) F[l].R -= (rS - rA) * K.B1, H[l].R -= (rS - rA) * K.B1;
+		--m;
+		prev_st_ = m >> 4, prev_st0 = m, prev_up = m + (nblkB << 4), prev_en0 = m + w;
 	}
+	for (; r <= rend; ++r) snapshot(r), generic_row(r);
 	return Rf;
 }
 
