@@ -558,6 +558,19 @@ __device__ __forceinline__ void gdw_cone_row_half(WaveHalf &H, const WaveK &K, b
 	prev_st_ = W.st_, prev_st0 = W.st0, prev_up = W.up;
 }
 
+// one anti-diagonal of an interior chunk (H.SEL = "all eight scores are fresh", set by the caller)
+__device__ __forceinline__ void gdw_cone_row_half_fast(WaveHalf &H, const WaveK &K, bool any_tn, int r, int qlen, const uint8_t *query, int hb0, int lane, uint8_t *pr)
+{
+	WaveRow W;
+	W.r = r, W.use_array = 1; // (no lane holds the first block of the window: nothing else of W is read)
+	const u32 pX = gdw_ror1<64>(H.X[3]), pV = gdw_ror1<64>(H.V[3]), pX2 = gdw_ror1<64>(H.X2[3]), pQ = gdw_ror1<64>(H.Qc[1]);
+	gdw_shift_query_half(H, pQ, lane == 0, gdw_seam_byte(query, qlen, r - (hb0 << 3)));
+	gdw_update_scores_half(H, K, any_tn);
+	u32 out[2];
+	gdw_compute_half<true>(H, K, W, pX, pV, pX2, out);
+	*reinterpret_cast<uint2 *>(pr + (lane << 3)) = make_uint2(out[0], out[1]);
+}
+
 __global__ __launch_bounds__(128) void ksw_extd2_wave128c_kernel(const KswTask *__restrict__ tasks,
                                                                  const int32_t *__restrict__ task_ids, int n_tasks,
                                                                  const uint8_t *__restrict__ qseq,
@@ -919,7 +932,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void k
 			gdw_band_uniform(r0 - 1, qlen, tlen, w, st0, en0);
 			prev_st_ = st0 >> 4, prev_st0 = st0, prev_up = st0 + (((en0 - st0 + 16) >> 4) << 4);
 		}
-		for (int r = r0; r <= r1; ++r) gdw_cone_row_half(Hc, K, any_tn, r, qlen, tlen, w, query, hb0, lane, prev_st_, prev_st0, prev_up, chunk + (size_t)(r - r0) * 512);
+		if (gdw_cone_interior_half(r0, r1, hb0, qlen, tlen, w)) { // (wave-uniform; almost every chunk of a read whose walk stays away from the band's edges)
+			Hc.SEL[0] = Hc.SEL[1] = 0x07060504u;
+			for (int r = r0; r <= r1; ++r) gdw_cone_row_half_fast(Hc, K, any_tn, r, qlen, query, hb0, lane, chunk + (size_t)(r - r0) * 512);
+		} else
+			for (int r = r0; r <= r1; ++r) gdw_cone_row_half(Hc, K, any_tn, r, qlen, tlen, w, query, hb0, lane, prev_st_, prev_st0, prev_up, chunk + (size_t)(r - r0) * 512);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
 		gd_walk_rows(Wk, *Tp, chunk, r0, qlen, tlen, w, cigar, lane, 512, hb0, true);
 	}

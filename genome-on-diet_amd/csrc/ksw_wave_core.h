@@ -381,6 +381,21 @@ GDW_HD void gdw_steady_rows(int qlen, int tlen, int w, int &rA, int &rS)
 	rS = rS > rA ? rA + ((rS - rA) & ~1) : rA;
 }
 
+// Is the chunk [r0, r1] of the half-block cone [hb0, hb0 + 63] INTERIOR: every row in the middle part of the alignment
+// (gdw_steady_rows) and all 512 cells of the cone, on every row, inside the cells whose scores are rewritten ([st0, up)) and inside the
+// computed blocks (<= en_)?  Then no lane ever is the first block, resets a cell or keeps a stale score, and the rows need no band
+// arithmetic at all (gdw_cone_row_half_fast).  st0 and en0 never decrease, and up >= st0 + 16 * nblkA on both rows of a pair.
+GDW_HD bool gdw_cone_interior_half(int r0, int r1, int hb0, int qlen, int tlen, int w)
+{
+	int rA, rS;
+	gdw_steady_rows(qlen, tlen, w, rA, rS);
+	if (r0 < rA || r1 >= rS || r0 <= 0) return false;
+	int st0a, en0a, st0b, en0b;
+	gd_band(r0, qlen, tlen, w, st0a, en0a);
+	gd_band(r1, qlen, tlen, w, st0b, en0b);
+	const int nblkA = (w - 1 + 16) >> 4;
+	return 8 * hb0 >= st0b && 8 * (hb0 + 64) <= st0a + 16 * nblkA && ((hb0 + 63) >> 1) <= (en0a >> 4);
+}
 // ---- score tracking ----------------------------------------------------------------------------------------
 // sum of the 16 V keys / of the U keys of cells 1..15 of a lane (horizontal step across a block)
 GDW_HD int gdw_sum16(const u32 A[8])

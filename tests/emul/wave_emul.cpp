@@ -18,6 +18,7 @@
 struct EmuResult { int score; std::vector<uint32_t> cigar; };
 
 // lock-step emulation of ksw_extd2_wave_kernel<LANES>; mirrors the device row loop statement by statement
+static long g_fast_chunks = 0; // chunks of the half-block cone that took the interior fast path
 static bool g_single = false; // argv[4] == "single": the single-affine (ksw_extz2) form of the kernel against the extz2 oracle
 
 static EmuResult emulate(int LANES, const uint8_t *query, int qlen, const uint8_t *target, int tlen, int w, const KswConst &C)
@@ -428,7 +429,29 @@ static EmuResult emulate_ckpt(const uint8_t *query, int qlen, const uint8_t *tar
 			pst_ = st0 >> 4, pst0 = st0, pup = st0 + (((en0 - st0 + 16) >> 4) << 4);
 		}
 		std::vector<uint8_t> buf((size_t)(r1 - r0 + 1) * 512, 0xEE), valid((size_t)(r1 - r0 + 1) * 64, 0);
-		for (int r = r0; r <= r1; ++r) {
+		const bool interior = gdw_cone_interior_half(r0, r1, hb0, qlen, tlen, w); // gdw_cone_row_half_fast
+		if (interior) ++g_fast_chunks;
+		for (int r = r0; r <= r1 && interior; ++r) {
+			if (r == r0) for (int l = 0; l < 64; ++l) Cn[l].SEL[0] = Cn[l].SEL[1] = 0x07060504u;
+			WaveRow W;
+			W.r = r, W.use_array = 1;
+			u32 pX[64], pV[64], pX2[64], pQ[64];
+			for (int l = 0; l < 64; ++l) {
+				const int p = (l + 63) % 64;
+				pX[l] = Cn[p].X[3], pV[l] = Cn[p].V[3], pX2[l] = Cn[p].X2[3], pQ[l] = Cn[p].Qc[1];
+			}
+			for (int l = 0; l < 64; ++l) {
+				gdw_shift_query_half(Cn[l], pQ[l], l == 0, gdw_qbyte(query, qlen, r - hb0 * 8));
+				gdw_update_scores_half(Cn[l], K, any_tn);
+			}
+			for (int l = 0; l < 64; ++l) {
+				u32 out[2];
+				gdw_compute_half<true>(Cn[l], K, W, pX[l], pV[l], pX2[l], out);
+				memcpy(&buf[(size_t)(r - r0) * 512 + l * 8], out, 8);
+				valid[(size_t)(r - r0) * 64 + l] = 1;
+			}
+		}
+		for (int r = r0; r <= r1 && !interior; ++r) {
 			WaveRow W;
 			W.r = r;
 			gd_band(r, qlen, tlen, w, W.st0, W.en0);
@@ -639,6 +662,6 @@ int main(int argc, char **argv)
 		}
 		free(ez.cigar);
 	}
-	printf("wave_emul lanes=%d pairs_run=%d skipped=%d mismatches=%d\n", LANES, n_run, n_skip, n_bad);
+	printf("wave_emul lanes=%d pairs_run=%d skipped=%d mismatches=%d fast_cone_chunks=%ld\n", LANES, n_run, n_skip, n_bad, g_fast_chunks);
 	return n_bad ? 1 : (n_run ? 0 : 3);
 }
