@@ -54,8 +54,9 @@ struct gdiet_ctx {
 	bool single_affine = false;        // set for the duration of a gdiet_hip_ksw_extz2_batch call: single-affine kernel variants
 	std::vector<int32_t> h_ids;
 	// per-read mapping path (map_pipeline.hip.h)
-	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack, m_post;
+	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack, m_post, m_seedids;
 	std::vector<uint8_t> h_vo;  // host copy of the vote records' heads, kept between batches
+	DevBuf h_pin; // page-locked: scores, CIGAR lengths and P1 results of a wide-band batch, written by map_post_kernel itself
 	DevBuf h_boxes, h_cand, h_tasks, h_seedout, h_res, h_cig, h_post; // HOST buffers kept between batches (gd_host_grow): the per-batch tables of a
 	                                                           // short-read batch are tens of MB each, and allocated fresh they cost page faults
 	int host_threads = 8;
@@ -248,9 +249,10 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar,
 	                  &ctx->m_sc, &ctx->m_mv, &ctx->m_u64, &ctx->m_seed, &ctx->m_seedout, &ctx->m_voteout, &ctx->m_hitoff, &ctx->m_hits,
-	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post};
+	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post, &ctx->m_seedids};
 	for (DevBuf *b : bufs)
 		if (b->p) (void)hipFree(b->p);
+	if (ctx->h_pin.p) (void)hipHostFree(ctx->h_pin.p);
 	DevBuf *hosts[] = {&ctx->h_boxes, &ctx->h_cand, &ctx->h_tasks, &ctx->h_seedout, &ctx->h_res, &ctx->h_cig, &ctx->h_post};
 	for (DevBuf *b : hosts) free(b->p);
 	for (int i = 0; i < 4; ++i)

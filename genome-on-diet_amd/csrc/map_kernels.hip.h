@@ -321,7 +321,8 @@ __global__ __launch_bounds__(64) void map_pack_cigar_kernel(int nb, const uint32
 struct MapPostOpt { int8_t mat[25]; int8_t q, e; int32_t log_gap; };
 __global__ __launch_bounds__(64) void map_post_kernel(int nb, const MapBox *__restrict__ boxes, const uint8_t *__restrict__ qbuf, const uint8_t *__restrict__ tbuf,
                                                       const int64_t *__restrict__ coff, uint32_t *__restrict__ cig, int32_t *__restrict__ n_cigar,
-                                                      const int32_t *__restrict__ score, MapPostOpt O, GdPostOut *__restrict__ post)
+                                                      const int32_t *__restrict__ score, MapPostOpt O, GdPostOut *__restrict__ post,
+                                                      int32_t *__restrict__ x_score, int32_t *__restrict__ x_ncig /* both given: post, x_score, x_ncig are page-locked HOST memory */)
 {
 	const int b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= nb) return;
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(64) void map_post_kernel(int nb, const MapBox *__re
 		n_cigar[b] = (int32_t)n;
 	}
 	post[b] = P;
+	if (x_score) x_score[b] = score[b], x_ncig[b] = n_cigar[b]; // the batch's results leave with this kernel: no copy afterwards (map_pipeline.hip.h)
 }
 
 // ---- wave-parallel form of map_seed_kernel: one 64-lane wavefront per read -------------------------------------------
@@ -415,10 +417,11 @@ __device__ __forceinline__ unsigned map_par_sketch(const uint8_t *str, unsigned 
 
 __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const uint8_t *__restrict__ reads, const int64_t *__restrict__ roff,
                                                            GdIdxView I, MapDevOpt O, const MapReadScratch *__restrict__ sc, GdMini *__restrict__ mv_arena,
-                                                           uint64_t *__restrict__ u64_arena, GdSeed *__restrict__ seed_arena, MapSeedOut *__restrict__ out)
+                                                           uint64_t *__restrict__ u64_arena, GdSeed *__restrict__ seed_arena, MapSeedOut *__restrict__ out,
+                                                           const int32_t *__restrict__ ids /* the reads of this launch (null: 0 .. n_reads - 1) */)
 {
-	const int rid = blockIdx.x;
-	if (rid >= n_reads) return;
+	if ((int)blockIdx.x >= n_reads) return;
+	const int rid = ids ? ids[blockIdx.x] : (int)blockIdx.x;
 	const unsigned lane = threadIdx.x;
 	const uint8_t *str = reads + roff[rid];
 	const int len = (int)(roff[rid + 1] - roff[rid]);

@@ -430,6 +430,32 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		while (cap < MAP_SORT_CAP_MAX && cap < est) cap <<= 1;
 		D.sort_cap = cap;
 	}
+	// Reads of very different lengths (ONT: log-normal up to 150 kbp): one launch per capacity class, each read in the class its own
+	// length asks for, so that a 30 kbp read does not hold the 128 KB of LDS the longest read of the batch needs -- 128 KB is one
+	// wavefront per CU, and never beside a DP kernel that keeps 48 KB of it.  (A read is treated exactly as if it were the longest read
+	// of its batch: every path of the kernel is exact, the capacity only selects between them.)
+	std::vector<int32_t> seed_ids;
+	std::vector<std::pair<int, int>> seed_classes; // (capacity, reads), longest class first; empty: one launch over all reads
+	if (D.sort_cap > MAP_SORT_CAP && n > 1) {
+		std::vector<int> cap_of(n);
+		int n_cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int i = 0; i < n; ++i) {
+			const double est = 1.25 * 2.0 / (O.w + 1) * gd_diet_len(O.pat, (unsigned)(B.roff[i + 1] - B.roff[i]), 0);
+			int cap = MAP_SORT_CAP, c = 0;
+			while (cap < MAP_SORT_CAP_MAX && cap < est) cap <<= 1, ++c;
+			cap_of[i] = c, ++n_cls[c];
+		}
+		int used = 0;
+		for (int c = 0; c < 8; ++c) used += n_cls[c] > 0;
+		if (used > 1) {
+			seed_ids.reserve(n);
+			for (int c = 7; c >= 0; --c) {
+				if (!n_cls[c]) continue;
+				seed_classes.push_back({MAP_SORT_CAP << c, n_cls[c]});
+				for (int i = 0; i < n; ++i) if (cap_of[i] == c) seed_ids.push_back(i);
+			}
+		}
+	}
 	D.sr.min_cnt = O.min_cnt, D.sr.rec_threshold_frac = O.rec_threshold_frac, D.sr.bw_frac = O.bw_frac, D.sr.bw_min = O.bw_min, D.sr.bw_max = O.bw_max;
 	D.sr.af_max_loc = O.af_max_loc, D.sr.max_nb_seeds = D.max_nb_seeds, D.sr.frag_mode = (O.flag & GD_F_FRAG_MODE) != 0;
 	const uint8_t *d_reads = (const uint8_t *)B.d_reads;
@@ -447,9 +473,22 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		if (ctx->seed_thread_kernel == 1 || (ctx->seed_thread_kernel == 0 && (B.roff[n] - B.roff[0]) / n < 1024))
 			hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
-		else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
+		else if (!seed_classes.empty()) { // one read per wavefront, one launch per LDS capacity class
+			if ((rc = gd_grow(ctx, ctx->m_seedids, sizeof(int32_t) * (size_t)n))) return rc;
+			GD_HIP(hipMemcpyAsync(ctx->m_seedids.p, seed_ids.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+			int at = 0;
+			for (const auto &cls : seed_classes) {
+				MapDevOpt Dc = D;
+				Dc.sort_cap = cls.first;
+				const size_t lds_c = std::max<size_t>((size_t)O.w * 64 * sizeof(GdMini), (size_t)cls.first * sizeof(uint64_t));
+				Dc.seed_lds = (uint32_t)lds_c;
+				hipLaunchKernelGGL(map_seed_wave_kernel, dim3(cls.second), dim3(64), lds_c, s, cls.second, d_reads, d_roff, ix->dview, Dc, (const MapReadScratch *)ctx->m_sc.p,
+				                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p, (const int32_t *)ctx->m_seedids.p + at);
+				at += cls.second;
+			}
+		} else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
 			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), seed_lds, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
-			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
+			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p, (const int32_t *)nullptr);
 		GD_HIP(hipMemcpyAsync(so, ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
 		GD_HIP(gd_stream_wait(ctx, s));
 		bool overflow = false;
@@ -573,7 +612,9 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	const bool post_dev = ctx->post_on_device != 0;
 	if (post_dev && (rc = gd_host_grow(ctx, ctx->h_post, sizeof(GdPostOut) * (size_t)std::max(nb, 1)))) return rc;
 	const GdPostOut *h_post = (const GdPostOut *)ctx->h_post.p;
+	static const bool no_export = getenv("GDIET_POST_EXPORT") && atoi(getenv("GDIET_POST_EXPORT")) == 0;
 	uint32_t *h_cig = nullptr;
+	bool exported = false; // the DP results came to the host with map_post_kernel's own stores
 	std::vector<int64_t> poff(1, 0);
 	// an async lane shares its parent's backtrace arena (two whole-batch arenas do not fit in HBM, and concurrent DP kernels of
 	// smaller batches measured slower): the DP stages take turns
@@ -622,11 +663,35 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			const int g_ = O.a, bb_ = O.b < 0 ? O.b : -O.b;
 			for (int i = 0; i < 25; ++i) PO.mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? (int8_t)g_ : (int8_t)bb_);
 			PO.q = (int8_t)O.q, PO.e = (int8_t)O.e, PO.log_gap = !(O.flag & GD_F_SR);
-			hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
-			                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p);
-			GD_HIP(hipMemcpyAsync(ctx->h_post.p, ctx->m_post.p, sizeof(GdPostOut) * (size_t)nb, hipMemcpyDeviceToHost, sd));
+			// A batch of wide-band alignments (the checkpointed kernels: four wavefronts of 128 registers per SIMD, i.e. no room for anything
+			// else while they run): the device-to-host copies below are kernels of the runtime and would start only when DP wavefronts of
+			// the NEXT batch retire -- ~1 s for 400 KB, and that second is part of the lane's cycle (kernel trace of the ONT path, round 2).
+			// map_post_kernel starts in the gap between the two DP kernels, so it writes the results to page-locked host memory itself.
+			const bool xport = (ctx->last_mask & 8) != 0 && !no_export;
+			if (xport) {
+				const size_t need = sizeof(GdPostOut) * (size_t)nb + sizeof(int32_t) * 2 * nbp + 256;
+				if (need > ctx->h_pin.cap) {
+					if (ctx->h_pin.p) (void)hipHostFree(ctx->h_pin.p);
+					ctx->h_pin.p = nullptr, ctx->h_pin.cap = 0;
+					if (hipHostMalloc(&ctx->h_pin.p, need + need / 2, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->h_pin.p = nullptr; }
+					else ctx->h_pin.cap = need + need / 2;
+				}
+			}
+			if (xport && ctx->h_pin.p) {
+				int32_t *x_score = (int32_t *)ctx->h_pin.p, *x_ncig = x_score + nbp;
+				GdPostOut *x_post = (GdPostOut *)(x_ncig + nbp);
+				hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+				                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, x_post, x_score, x_ncig);
+				h_score = x_score, h_ncig = x_ncig, h_post = x_post;
+				exported = true;
+			} else {
+				hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+				                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p,
+				                   (int32_t *)nullptr, (int32_t *)nullptr);
+				GD_HIP(hipMemcpyAsync(ctx->h_post.p, ctx->m_post.p, sizeof(GdPostOut) * (size_t)nb, hipMemcpyDeviceToHost, sd));
+			}
 		}
-		GD_HIP(hipMemcpyAsync(h_score, d_score, sizeof(int32_t) * 2 * nbp, hipMemcpyDeviceToHost, sd));
+		if (!exported) GD_HIP(hipMemcpyAsync(h_score, d_score, sizeof(int32_t) * 2 * nbp, hipMemcpyDeviceToHost, sd));
 		GD_HIP(gd_stream_wait(ctx, sd));
 	mark("d:wait");
 		// CIGARs are short compared with their capacity (qlen+tlen): pack them on the device, then one copy
