@@ -731,6 +731,17 @@ extern "C" int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *bt_
 
 // ---- host-pointer entry point ------------------------------------------------------------------------------
 
+// The synchronous kernel-level entry points grow and write the context's arena / sequence buffers on ctx->stream; the batches in flight
+// of gdiet_hip_map_submit share that arena (dp_mu / arena_ev), so such a call while tickets are open could free the arena under a
+// lane's running DP kernel.  Refused, as gdiet_hip_map_uploaded refuses it.
+static bool gd_tickets_open(gdiet_ctx *ctx)
+{
+	std::lock_guard<std::mutex> guard(ctx->async_mu);
+	for (int i = 0; i < 4; ++i)
+		if (ctx->async_busy[i]) { ctx->err = "batches submitted with gdiet_hip_map_submit are still in flight: wait for their tickets first"; return true; }
+	return false;
+}
+
 extern "C" int gdiet_hip_ksw_extd2_batch(gdiet_ctx *ctx, int n, const uint8_t *qseq, const int64_t *qoff,
                                          const uint8_t *tseq, const int64_t *toff, const int32_t *w,
                                          const int32_t *exact_score, const gdiet_ksw_score_t *sc, int32_t *score,
@@ -742,6 +753,7 @@ extern "C" int gdiet_hip_ksw_extd2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 		ctx->err = "NULL argument";
 		return GDIET_E_PARAM;
 	}
+	if (gd_tickets_open(ctx)) return GDIET_E_PARAM;
 	(void)hipSetDevice(ctx->device);
 	int rc;
 	hipStream_t s = ctx->stream;
@@ -804,6 +816,7 @@ extern "C" int gdiet_hip_ksw_extz2_batch_ex(gdiet_ctx *ctx, int n, const uint8_t
 		return GDIET_E_PARAM;
 	}
 	static_assert(sizeof(gdiet_ksw_extz_t) == sizeof(GdExtzOut), "public and kernel record differ");
+	if (gd_tickets_open(ctx)) return GDIET_E_PARAM;
 	(void)hipSetDevice(ctx->device);
 	hipStream_t s = ctx->stream;
 	KswzConst K;
@@ -876,6 +889,7 @@ extern "C" int gdiet_hip_ksw_exts2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 	                      GD_EZ_SPLICE_FOR | GD_EZ_SPLICE_REV | GD_EZ_SPLICE_FLANK;
 	if (flag & ~known) { ctx->err = "gdiet_hip_ksw_exts2_batch: unknown flag bit"; return GDIET_E_PARAM; }
 	if (q2 <= q + e || e <= 0) { ctx->err = "ksw_exts2 needs q2 > q + e (and e > 0): the reference returns without aligning"; return GDIET_E_PARAM; } // :72
+	if (gd_tickets_open(ctx)) return GDIET_E_PARAM;
 	(void)hipSetDevice(ctx->device);
 	hipStream_t s = ctx->stream;
 	KswsConst K;
@@ -956,6 +970,7 @@ extern "C" int gdiet_hip_lchain_dp_batch(gdiet_ctx *ctx, int n_reads, const uint
 		n_u[i] = 0, n_v[i] = 0;
 	}
 	if (tot == 0) return GDIET_OK;
+	if (gd_tickets_open(ctx)) return GDIET_E_PARAM;
 	(void)hipSetDevice(ctx->device);
 	hipStream_t s = ctx->stream;
 	GdChainOpt O;

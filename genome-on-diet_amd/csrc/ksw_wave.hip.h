@@ -466,7 +466,7 @@ __device__ __forceinline__ void gdw_lane_load(WaveLane &L, const u32 *d)
 // ---- second pass of the checkpointed form: only the CONE of the walk is recomputed ---------------------------------------------
 // A walk that enters a chunk at cell (i1, r1) moves down by at most one target position per anti-diagonal, so inside the chunk it
 // stays within t in [i1 - (r1 - r), i1] on row r; and a cell (r, t) depends on (r-1, t-1) and (r-1, t) only, so those cells depend
-// on nothing outside that same cone.  With at most GD_CK_ROWS = 960 rows the cone spans <= 62 blocks: the second pass recomputes
+// on nothing outside that same cone.  With at most GD_CK_ROWS = 480 rows the cone spans <= 31 blocks (62 half blocks): the second pass recomputes
 // the 64 blocks [b0, b0 + 63], b0 = (i1 >> 4) - 63, ONE per lane and without a ring (half the instructions of the two-blocks-per-
 // lane row), restored from the snapshot of the chunk.  Cells of those blocks below the cone come out wrong (their t-1 inputs are
 // not computed) and are never read: wrongness spreads upwards by one cell per row, exactly as fast as the cone's lower edge.

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(64) void lchain_fill_kernel(int n_reads, const uint
 			}
 			__syncthreads();
 		}
-		if (max_ii < 0 || (int64_t)(aix - A[2 * max_ii]) > (int64_t)O.max_dist_x) { // :165-170: the best f in the window, the largest j among equals
+		// (the distance test is UNSIGNED, as in the reference, whose uint64 operand wins the conversion: where the anchors pass from one
+		// target or strand to the next -- minimap2 keeps the strand in bit 63 -- the difference wraps to >= 2^63 and forces the rescan)
+		if (max_ii < 0 || (uint64_t)(aix - A[2 * max_ii]) > (uint64_t)(int64_t)O.max_dist_x) { // :165-170: the best f in the window, the largest j among equals
 			int32_t bf = INT32_MIN;
 			int bj = -1;
 			for (int j = i - 1 - lane; j >= st; j -= 64) {
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(64) void lchain_fill_kernel(int n_reads, const uint
 		}
 		const int32_t vi = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 		if (lane == 0) f[i] = max_f, p[i] = max_j, v[i] = vi;
-		if (max_ii < 0 || ((int64_t)(aix - A[2 * max_ii]) <= (int64_t)O.max_dist_x && f[max_ii] < max_f)) max_ii = i;
+		if (max_ii < 0 || ((uint64_t)(aix - A[2 * max_ii]) <= (uint64_t)(int64_t)O.max_dist_x && f[max_ii] < max_f)) max_ii = i;
 		__threadfence_block();
 		__syncthreads();
 	}

@@ -489,6 +489,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		} else // one read per wavefront: 64 exact slices of the winnowing automaton + parallel index probes
 			hipLaunchKernelGGL(map_seed_wave_kernel, dim3(n), dim3(64), seed_lds, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p, (const int32_t *)nullptr);
+		GD_HIP(hipGetLastError()); // a refused launch (LDS size, grid) must not pass for stale seed records
 		GD_HIP(hipMemcpyAsync(so, ctx->m_seedout.p, sizeof(MapSeedOut) * n, hipMemcpyDeviceToHost, s));
 		GD_HIP(gd_stream_wait(ctx, s));
 		bool overflow = false;
@@ -514,6 +515,10 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		for (int i = 0; i < n; ++i) max_hits = std::max(max_hits, hoff[i + 1] - hoff[i]);
 		unsigned vote_cap = 256;
 		while (vote_cap < MAP_VOTE_CAP && (int64_t)vote_cap < max_hits) vote_cap <<= 1;
+		// the kernel also holds static LDS (its candidate list): with the full sort buffer the total passes 64 KB, which a launch is
+		// only granted after the attribute has been raised
+		if (sizeof(GdLoc) * (size_t)vote_cap + sizeof(GdVt) * GDM_MAX_VT + 64 > 64 * 1024)
+			GD_HIP(hipFuncSetAttribute((const void *)map_vote_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(GdLoc) * (size_t)vote_cap)));
 		hipLaunchKernelGGL(map_vote_wave_kernel, dim3(n), dim3(64), sizeof(GdLoc) * (size_t)vote_cap, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 		                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
 		                   (MapVoteOut *)ctx->m_voteout.p, vote_cap);
@@ -521,6 +526,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		hipLaunchKernelGGL(map_vote_kernel, dim3(spread ? n : (n + 63) / 64), dim3(64), 0, s, n, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 		                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
 		                   (MapVoteOut *)ctx->m_voteout.p, spread);
+	GD_HIP(hipGetLastError());
 	// only the head of every record can be in use: n_cand + at most AF_max_loc (ShortReads) / vt_nb_loc + 2 (LongReads) candidates;
 	// the host copy is packed to that size (a full-size array would be 680 B per read: 178 MB to allocate and clear per 262 k short reads)
 	const size_t vo_head = offsetof(MapVoteOut, cand) + sizeof(GdVt) * std::min<size_t>(is_sr ? (size_t)O.af_max_loc : (size_t)O.vt_nb_loc + 2, GDM_MAX_VT);

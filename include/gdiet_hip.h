@@ -143,7 +143,8 @@ int gdiet_hip_ksw_exts2_batch(gdiet_ctx *ctx, int n,
 /* ---- SURVEY 8f rank 4 (chaining half): batched anchor chaining ------------------------------------------------------------
  * Replaces mg_lchain_dp (SR/lchain.c:124-190, SR/mmpriv.h:102-104) for a batch of reads; like ksw_exts2 it is code of minimap2
  * that GDiet keeps and never calls (GDiet votes instead of chaining), provided for a minimap2-compatible mode.  a = the
- * anchors of all reads as (x, y) pairs of uint64 (x: tid<<33 | rev<<32 | tpos, y: flags<<40 | q_span<<32 | q_pos; per read
+ * anchors of all reads as (x, y) pairs of uint64 (x: rev<<63 | tid<<32 | tpos -- minimap2's layout, SR/hit.c:26; any layout whose
+ * upper 32 bits name the target + strand and whose lower 32 bits are the position chains alike --, y: flags<<40 | q_span<<32 | q_pos; per read
  * sorted by x as minimap2 sorts them), read i = pairs aoff[i] .. aoff[i+1]; the scalar parameters are the reference's.
  * Outputs, per read at the read's own offset (a chain set never has more chains or anchors than the read has anchors):
  * n_u[i] chains, u[aoff[i] + k] = score<<32 | n_anchors of chain k, a_out (pairs, at 2 * aoff[i]) = the chains' anchors, n_v[i]

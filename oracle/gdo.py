@@ -284,8 +284,15 @@ def same_lchain(o, r):
 
 def lchain_cases(rng, n_cases):
     """yield (anchors uint64[n, 2] sorted by x, parameter dict): a few colinear runs per target / strand with indel drift, repeats
-    (anchors sharing query or target positions), noise anchors, sometimes two query segments (paired-end style) or cDNA-like jumps"""
+    (anchors sharing query or target positions), noise anchors, sometimes two query segments (paired-end style) or cDNA-like jumps.
+    Two cases in three carry minimap2's own anchor layout x = rev<<63 | tid<<32 | tpos (SR/hit.c:26: r->rev = a[k].x>>63), where the
+    first anchor of the reverse strand lies >= 2^63 above the last forward one -- the unsigned distance test of SR/lchain.c:165,177
+    then forces a rescan; the others keep tid<<33 | strand<<32 | tpos, where consecutive groups differ by 2^32"""
     for ci in range(n_cases):
+        mm2 = ci % 3 != 0
+
+        def X(rid, strand, tpos):
+            return (strand << 63 | rid << 32 | (tpos & 0x7fffffff)) if mm2 else (rid << 33 | strand << 32 | (tpos & 0x7fffffff))
         k = int(rng.choice([11, 15, 19]))
         n_seg = 2 if ci % 9 == 4 else 1
         is_cdna = int(ci % 7 == 3)
@@ -302,13 +309,13 @@ def lchain_cases(rng, n_cases):
                         qpos += step
                         if rng.random() < 0.03 and n_seg > 1:
                             seg ^= 1
-                        xs.append(rid << 33 | strand << 32 | (tpos & 0x7fffffff))
+                        xs.append(X(rid, strand, tpos))
                         ys.append(seg << 48 | k << 32 | (qpos & 0x7fffffff))
                         if rng.random() < 0.05:  # a repeat: same query position elsewhere on the target
-                            xs.append(rid << 33 | strand << 32 | ((tpos + int(rng.integers(1, 500))) & 0x7fffffff))
+                            xs.append(X(rid, strand, tpos + int(rng.integers(1, 500))))
                             ys.append(seg << 48 | k << 32 | (qpos & 0x7fffffff))
         for _ in range(int(rng.integers(0, 40))):  # noise
-            xs.append(int(rng.integers(0, 3)) << 33 | int(rng.integers(0, 2)) << 32 | int(rng.integers(0, 200000)))
+            xs.append(X(int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.integers(0, 200000))))
             ys.append(int(rng.integers(0, n_seg)) << 48 | k << 32 | int(rng.integers(0, 5000)))
         a = np.array(list(zip(xs, ys)), np.uint64).reshape(-1, 2)
         if len(a):

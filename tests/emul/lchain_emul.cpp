@@ -37,7 +37,7 @@ extern "C" int lchain_emul(int64_t n, const uint64_t *a_, int max_dist_x, int ma
 			if (p[j] >= 0) t[p[j]] = (int32_t)i;
 		}
 		end_j = j;
-		if (max_ii < 0 || (int64_t)(a[i].x - a[max_ii].x) > (int64_t)O.max_dist_x) {
+		if (max_ii < 0 || (uint64_t)(a[i].x - a[max_ii].x) > (uint64_t)(int64_t)O.max_dist_x) { // unsigned, as SR/lchain.c:165
 			int32_t mx = INT32_MIN;
 			max_ii = -1;
 			for (j = i - 1; j >= st; --j)
@@ -49,7 +49,7 @@ extern "C" int lchain_emul(int64_t n, const uint64_t *a_, int max_dist_x, int ma
 		}
 		f[i] = max_f, p[i] = (int32_t)max_j;
 		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
-		if (max_ii < 0 || ((int64_t)(a[i].x - a[max_ii].x) <= (int64_t)O.max_dist_x && f[max_ii] < f[i])) max_ii = i;
+		if (max_ii < 0 || ((uint64_t)(a[i].x - a[max_ii].x) <= (uint64_t)(int64_t)O.max_dist_x && f[max_ii] < f[i])) max_ii = i;
 	}
 	std::vector<GdlPair> z, b;
 	std::vector<int32_t> tt;

@@ -63,7 +63,7 @@ int main(int argc, char **argv)
 	O.flag = GD_F_NO_PRINT_2ND * 0;
 	std::vector<const char *> pos;
 	const char *mmi_in = nullptr, *mmi_out = nullptr;
-	bool trace = false, out_sam = false;
+	bool trace = false, out_sam = false, stats = false;
 	int n_threads = 1;
 	bool preset_seen = false, sr_variant = false;
 	auto preset = [&](const char *p) -> bool {
@@ -126,9 +126,14 @@ int main(int argc, char **argv)
 				if (pass) { char *e; O.min_cnt = strtof(v, &e); if (*e == ',') O.rec_threshold_frac = strtof(e + 1, &e); }
 			}
 			else if ((v = val("AF_max_loc"))) { if (pass) O.af_max_loc = (int)atof(v); }
+			else if (a == "--stats") { if (pass) stats = true; }          // count the events the repeat-rich fixtures exist for (oracle/make_golden.py prints them)
 			else if (a == "--print-seeds") { if (pass) trace = true; }   // the reference's stage trace (RS/SD/VT/AVT/BE/AL_SCORE lines, LR/map.c:1328-1338,1447-1459,1592-1602,1670-1675,1808-1810)
 			else if ((v = val("mmi"))) { if (pass) mmi_in = v; }           // use an .mmi written by the reference instead of building the index
 			else if ((v = val("dump-mmi"))) { if (pass) mmi_out = v; }    // write the index as an .mmi and exit
+			else if (a == "-f") { // LR/main.c:440-448: a fraction selects mid_occ from the index, a number >= 1 is mid_occ itself
+				v = argv[++i];
+				if (pass) { const double x = strtod(v, 0); if (x < 1.0) mid_occ_frac = (float)x, O.mid_occ = 0; else O.mid_occ = (int)(x + .499); }
+			}
 			else if (a == "-s") { v = argv[++i]; if (pass) O.min_dp_max = atoi(v); }
 			else if (a == "-N") { v = argv[++i]; if (pass) O.best_n = atoi(v); }
 			else if (a.compare(0, 2, "-F") == 0) { if (a.size() == 2) ++i; }
@@ -183,6 +188,8 @@ int main(int argc, char **argv)
 	for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? (int8_t)g : (int8_t)bb);
 	// reads are independent: a few worker threads, results printed in input order (the oracle's scalar DP is the slow part)
 	std::vector<std::string> sam_of(qs.size()), trace_of(qs.size());
+	// --stats: reads on which each high-occurrence branch of the seeding stage fires
+	std::atomic<long> st_mzflt{0}, st_mzflt_dropped{0}, st_high{0}, st_over_max{0}, st_heap_replace{0}, st_big_strand{0}, st_max_hits{0}, st_flt_rescued{0};
 	auto map_one = [&](size_t ri) {
 		std::string out;
 		char *tbuf = nullptr;
@@ -206,13 +213,45 @@ int main(int argc, char **argv)
 			const uint32_t cap = (O.flag & GD_F_FRAG_MODE) ? (O.max_frag_len == 0 ? 800u : (uint32_t)O.max_frag_len) : UINT32_MAX;
 			const unsigned tel = gd_sketch3(enc.data(), (unsigned)len, O.w, O.k, O.pat, shift, cap, mv.data(), maxm, &n_mv);
 			std::vector<uint64_t> scratch(2 * (size_t)n_mv + 2);
+			const unsigned n_mv0 = n_mv;
 			if (O.q_occ_frac > 0.0f) n_mv = gd_mz_flt(mv.data(), n_mv, O.mid_occ, O.q_occ_frac, scratch.data());
+			if (stats) {
+				if (n_mv < n_mv0) ++st_mzflt, st_mzflt_dropped += n_mv0 - n_mv;
+				// the seeds present in the index, in sketch order: streaks of n > mid_occ (LR/seed.c:66-106)
+				std::vector<std::pair<uint32_t, uint32_t>> pr; // (n, q_pos >> 1)
+				for (unsigned i = 0; i < n_mv; ++i) {
+					uint64_t st_;
+					const uint32_t n = gd_idx_get(V, mv[i].x >> 8, &st_);
+					if (n) pr.emplace_back(n, (uint32_t)mv[i].y >> 1);
+				}
+				bool high = false, over = false, repl = false, resc = false;
+				int last0 = -1;
+				for (int i = 0; i <= (int)pr.size(); ++i)
+					if (i == (int)pr.size() || (int32_t)pr[i].first <= O.mid_occ) {
+						if (i - last0 > 1) {
+							high = true;
+							const int ps = last0 < 0 ? 0 : (int)pr[last0].second, pe = i == (int)pr.size() ? len : (int)pr[i].second;
+							int mh = (int)((double)(pe - ps) / O.occ_dist + .499);
+							if (mh > 128) mh = 128;
+							if (mh > 0) resc = true;
+							if (mh > 0 && i - last0 - 1 > mh) repl = true;
+							for (int j = last0 + 1; j < i; ++j) over |= (int32_t)pr[j].first > O.max_max_occ;
+						}
+						last0 = i;
+					}
+				st_high += high, st_over_max += over, st_heap_replace += repl, st_flt_rescued += resc;
+			}
 			std::vector<GdSeed> seeds(n_mv + 1);
 			int64_t n_a = 0;
 			const int n_m = gd_collect_matches2(V, mv.data(), n_mv, len, O.mid_occ, O.max_max_occ, O.occ_dist, seeds.data(), &n_a);
 			std::vector<GdLoc> af(n_a + 1), ar(n_a + 1), tmp(n_a + 1);
 			unsigned nf = 0, nr = 0;
 			gd_seed_hits(V, seeds.data(), n_m, O.flag, tel, af.data(), ar.data(), &nf, &nr);
+			if (stats) {
+				if (nf > 4096 || nr > 4096) ++st_big_strand;
+				long cur = st_max_hits.load(), m = nf > nr ? nf : nr;
+				while (m > cur && !st_max_hits.compare_exchange_weak(cur, m)) {}
+			}
 			GdLoc *sf = gd_sort_locs(af.data(), tmp.data(), nf);
 			std::vector<GdLoc> sfv(sf, sf + nf);
 			GdLoc *sr = gd_sort_locs(ar.data(), tmp.data(), nr);
@@ -308,6 +347,18 @@ int main(int argc, char **argv)
 	for (int t = 0; t < n_threads; ++t)
 		workers.emplace_back([&] { for (size_t ri; (ri = next_read.fetch_add(1)) < qs.size();) map_one(ri); });
 	for (auto &w : workers) w.join();
+	if (stats) {
+		uint64_t over_mid = 0, over_max = 0, max_cnt = 0, multi = 0;
+		for (uint64_t s_ = 0; s_ < (1ull << V.tbits); ++s_)
+			if (V.tkey[s_] != UINT64_MAX) {
+				const uint32_t n = (uint32_t)V.tval[s_];
+				over_mid += (int64_t)n > O.mid_occ, over_max += (int64_t)n > O.max_max_occ, multi += n > 1, max_cnt = n > max_cnt ? n : max_cnt;
+			}
+		fprintf(stderr, "[stats] index: keys=%llu multi=%llu keys>mid_occ(%d)=%llu keys>max_max_occ(%d)=%llu max_count=%llu\n", (unsigned long long)I.n_keys, (unsigned long long)multi,
+		        O.mid_occ, (unsigned long long)over_mid, O.max_max_occ, (unsigned long long)over_max, (unsigned long long)max_cnt);
+		fprintf(stderr, "[stats] reads=%zu mz_flt_drops=%ld (minimizers dropped %ld) high_occ_streak=%ld rescue=%ld heap_replace=%ld over_max_max_occ=%ld strand>4096hits=%ld max_strand_hits=%ld\n",
+		        qs.size(), st_mzflt.load(), st_mzflt_dropped.load(), st_high.load(), st_flt_rescued.load(), st_heap_replace.load(), st_over_max.load(), st_big_strand.load(), st_max_hits.load());
+	}
 	for (size_t ri = 0; ri < qs.size(); ++ri) {
 		fputs(trace_of[ri].c_str(), stderr);
 		fputs(sam_of[ri].c_str(), stdout);

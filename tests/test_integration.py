@@ -62,7 +62,7 @@ def test_glue_fails_loudly_without_a_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["hifi", "hifi_sv", "ont_sv", "hifi_edge", "sr", "sr_var", "sr_edge"])
+@pytest.mark.parametrize("kind", ["hifi", "hifi_sv", "ont_sv", "hifi_edge", "sr", "sr_var", "sr_edge", "hifi_rep", "ont_rep", "sr_rep", "sr_rep_f60"])
 def test_patched_reference_binary_prints_the_golden_sam(kind, tmp_path):
     variant = "sr" if SETS[kind][2] == "sr" else "lr"
     exe = HIP_BIN[variant]

@@ -10,7 +10,8 @@ from fixture_io import LR, OVERRIDES, PAF_KINDS, SETS, golden_paf, golden_sam, r
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge", "hifi_sv", "ont_sv"])
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge", "hifi_sv", "ont_sv",
+                                  "hifi_rep", "ont_rep", "sr_rep", "sr_rep_f60"])
 def test_map_batch_matches_golden_sam(gpu_ctx, pkg, kind):
     base, stem, preset = SETS[kind]
     names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
@@ -185,7 +186,49 @@ def test_mmi_index_files(gpu_ctx, pkg, tmp_path):
         pkg.Mapper(gpu_ctx, names, seqs, preset="sr", w=65)
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont", "sr"])
+@pytest.mark.parametrize("kind,seed_kernel", [("hifi_rep", "thread"), ("ont_rep", "thread"), ("sr_rep", "wave"), ("sr_rep_f60", "wave")])
+def test_rep_sets_through_the_other_seed_executor(pkg, kind, seed_kernel, monkeypatch):
+    """the repeat-rich sets through the executor their read length does NOT select by default (GDIET_SEED_KERNEL: long reads one
+    per thread on the shared stage code, short reads one per wavefront with the LDS pre-check / wave compactions / LDS-run merge):
+    both executors of S4-S7 give the reference's SAM where minimizers are dropped, rescued and cut at max_max_occ"""
+    import torch  # noqa: F401
+    monkeypatch.setenv("GDIET_SEED_KERNEL", seed_kernel)
+    if seed_kernel == "thread":
+        monkeypatch.setenv("GDIET_VOTE_WAVE", "0")
+    ctx = pkg.Context(0)  # the executor is chosen when the context is created
+    base, stem, preset = SETS[kind]
+    names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+    reads = reads_of(kind)
+    m = pkg.Mapper(ctx, names, seqs, preset=preset, **OVERRIDES.get(kind, {}))
+    try:
+        res = m.map([r[1] for r in reads])
+        assert m.sam_batch(res, reads) == "".join(l + "\n" for l in golden_sam(kind))
+    finally:
+        m.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("tag,kind", [("k19w19", "hifi_rep"), ("k15w10", "ont_rep"), ("k21w11", "sr_rep")])
+def test_device_built_rep_mmi_is_the_reference_s(gpu_ctx, pkg, tmp_path, tag, kind):
+    """the index of the repeat-rich reference BUILT ON THE DEVICE and dumped: size and sha256 of the file `GDiet_avx -d` wrote for it
+    (tests/golden/rep/mmi.sha256.json) -- thousands of multi-occurrence position lists (p[] arrays), whose order comes from the two
+    stable device sorts, and khash buckets with non-singleton keys"""
+    import hashlib
+    import json
+    from fixture_io import REP
+    want = json.load(open(os.path.join(REP, "mmi.sha256.json")))[tag]
+    names, seqs = read_fasta(os.path.join(REP, "ref.fa.gz"))
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset=SETS[kind][2])
+    try:
+        out = str(tmp_path / "built.mmi")
+        m.dump_mmi(out)
+        data = open(out, "rb").read()
+        assert len(data) == want["size"] and hashlib.sha256(data).hexdigest() == want["sha256"]
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "hifi_rep", "ont_rep", "sr_rep"])
 def test_device_built_index_equals_host_built(gpu_ctx, pkg, kind, monkeypatch):
     """gdiet_hip_index_build on the device (sketch slices, radix sorts, run-length encode, CAS table) against the host builder:
     same keys, same counts, same position lists in the same order, same mid_occ"""

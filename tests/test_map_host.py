@@ -10,7 +10,7 @@ import subprocess
 import pytest
 
 from conftest import ROOT
-from fixture_io import LR, PAF_KINDS, SETS, SR, TRACE_PREFIXES, cmd_of, golden_paf, golden_sam, paf_cmd_of, reads_of, trace_of
+from fixture_io import LR, PAF_KINDS, REP, SD_DIGESTED, SETS, SR, TRACE_PREFIXES, cmd_of, digest_sd, golden_paf, golden_sam, paf_cmd_of, reads_of, trace_of
 
 
 @pytest.fixture(scope="module")
@@ -20,7 +20,7 @@ def host_driver(tmp_path_factory):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-w", "-I", os.path.join(ROOT, "genome-on-diet_amd", "csrc"),
                            "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "emul", "map_host_main.cpp"),
                            "-x", "c", os.path.join(ROOT, "oracle", "gdo_ksw2.c"), "-o", exe])
-    for sub, base, files in (("lr", LR, ("ref.fa", "hifi.fq", "ont.fq")), ("sr", SR, ("ref.fa", "sr.fq", "var.fq"))):
+    for sub, base, files in (("lr", LR, ("ref.fa", "hifi.fq", "ont.fq")), ("sr", SR, ("ref.fa", "sr.fq", "var.fq")), ("rep", REP, ("ref.fa",))):
         os.makedirs(str(d / sub))
         for f in files:
             with gzip.open(os.path.join(base, f + ".gz"), "rb") as src, open(str(d / sub / f), "wb") as dst:
@@ -31,7 +31,7 @@ def host_driver(tmp_path_factory):
 THREADS = ["-t", str(min(8, os.cpu_count() or 1))]
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge", "hifi_sv", "ont_sv"])
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge", "hifi_sv", "ont_sv", "hifi_rep", "ont_rep", "sr_rep", "sr_rep_f60"])
 def test_host_path_matches_golden_sam(host_driver, kind, tmp_path):
     exe, d = host_driver
     base = SETS[kind][0]
@@ -143,7 +143,7 @@ def _split_trace(lines):
             cur = {"shift": line, "RS": [], "SD": [], "VT": [], "AVT": [], "BE": [], "AL": [], "CON": []}
             per_read.append(cur)
         elif cur is not None:
-            for key, prefix in (("RS", "RS "), ("SD", "SD\t"), ("VT", "VT\t"), ("AVT", "AVT\t"), ("BE", "BE\t"), ("AL", "AL_SCORE"), ("CON", "CON")):
+            for key, prefix in (("RS", "RS "), ("SD", "SD\t"), ("SD", "SDX\t"), ("VT", "VT\t"), ("AVT", "AVT\t"), ("BE", "BE\t"), ("AL", "AL_SCORE"), ("CON", "CON")):
                 if line.startswith(prefix):
                     cur[key].append(line)
     for r in per_read:
@@ -151,28 +151,75 @@ def _split_trace(lines):
     return per_read
 
 
-@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "hifi_sv", "ont_sv"])
+@pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "hifi_sv", "ont_sv", "hifi_rep", "ont_rep", "sr_rep"])
 def test_stage_trace_matches_the_reference(host_driver, tmp_path, kind):
     """stage-level parity (the reference's --print-seeds trace, committed as <kind>.trace.gz by oracle/make_golden.py):
     chosen pattern phase, sorted seed hits of both strands, vote candidates before and after linking (second voting round
     included), DP boxes, DP scores and the CONQ / CONT line pairs of every concatenate_cigars call, line for line.  Hits with
-    equal targets may be ordered differently by the two sorts, so the SD lines are compared as a multiset per read."""
+    equal targets may be ordered differently by the two sorts, so the SD lines are compared as a multiset per read (for the
+    repeat-rich sets, whose reads have up to 280 000 hits per strand: as their count and the sha1 of the sorted lines)."""
     exe, d = host_driver
-    variant = "sr" if kind == "sr" else "lr"
-    ref_fa = os.path.join(d, variant, "ref.fa")
+    ref_fa = os.path.join(d, os.path.basename(SETS[kind][0]), "ref.fa")
     fq = str(tmp_path / "reads.fq")
     reads = reads_of(kind)
     with open(fq, "w") as f:
         for name, seq, qual in reads:
             f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
     err = subprocess.run([exe] + THREADS + cmd_of(kind) + ["--print-seeds", ref_fa, fq], capture_output=True, text=True, check=True).stderr
-    want, got = _split_trace(trace_of(kind)), _split_trace(l for l in err.split("\n") if l.startswith(TRACE_PREFIXES))
+    mine = [l for l in err.split("\n") if l.startswith(TRACE_PREFIXES)]
+    want, got = _split_trace(trace_of(kind)), _split_trace(digest_sd(mine) if kind in SD_DIGESTED else mine)
     assert len(want) == len(got) == len(reads)
     for a, b in zip(want, got):
         assert a == b
-    assert sum(len(r["SD"]) for r in want) > 100 and sum(len(r["VT"]) for r in want) > 0
+    assert sum(len(r["SD"]) for r in want) > (20 if kind in SD_DIGESTED else 100) and sum(len(r["VT"]) for r in want) > 0
     if kind.endswith("_sv"):  # the fixtures exist for these stages
         assert sum(len(r["CON"]) for r in want) >= 2 * 20
+
+
+# what each repeat-rich set must reach, as counted by the host emulator's --stats (every number a lower bound on the count of READS
+# on which the branch fires): mm_seed_mz_flt dropping minimizers (SR/seed.c:5-29); a streak of seeds above mid_occ with a rescue
+# budget (SR/seed.c:79-98) and with more seeds than the budget, i.e. the heap with replacement (:89-94); a seed above max_max_occ
+# (:101-102); a strand with more than 4096 hits (the wave vote kernel's LDS-run merge path, MAP_VOTE_CAP)
+REP_MUST_REACH = {"hifi_rep": dict(mz_flt_drops=10, rescue=20, heap_replace=10, over_max_max_occ=5, big_strand=50),
+                  "ont_rep": dict(mz_flt_drops=4, rescue=10, heap_replace=10, over_max_max_occ=5, big_strand=30),
+                  "sr_rep": dict(mz_flt_drops=0, rescue=5, heap_replace=5, over_max_max_occ=100, big_strand=50),
+                  "sr_rep_f60": dict(mz_flt_drops=5, rescue=10, heap_replace=10, over_max_max_occ=100, big_strand=1)}
+
+
+@pytest.mark.parametrize("kind", list(REP_MUST_REACH))
+def test_rep_fixtures_reach_the_high_occurrence_branches(host_driver, tmp_path, kind):
+    """the repeat-rich sets exist to make the high-occurrence branches of the seeding stage fire; count them (and the index keys
+    above mid_occ / max_max_occ) with the product's own stage code on the host"""
+    import re
+    exe, d = host_driver
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for name, seq, qual in reads_of(kind):
+            f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
+    err = subprocess.run([exe] + THREADS + cmd_of(kind) + ["--stats", os.path.join(d, "rep", "ref.fa"), fq], capture_output=True, text=True, check=True).stderr
+    st = dict(re.findall(r"([a-z_>0-9()]+)=(\d+)", " ".join(l for l in err.split("\n") if l.startswith("[stats]"))))
+    num = {k.split("(")[0]: int(v) for k, v in st.items()}
+    assert num["keys>mid_occ"] >= 5 and num["keys>max_max_occ"] >= 3 and num["multi"] >= 2000 and num["max_count"] > 4095
+    need = REP_MUST_REACH[kind]
+    assert num["mz_flt_drops"] >= need["mz_flt_drops"] and num["rescue"] >= need["rescue"] and num["heap_replace"] >= need["heap_replace"]
+    assert num["over_max_max_occ"] >= need["over_max_max_occ"] and num["strand>4096hits"] >= need["big_strand"]
+
+
+def test_rep_mmi_files_are_the_reference_s(host_driver, tmp_path):
+    """the .mmi writer on an index with thousands of multi-occurrence position lists (p[] arrays of up to 8 000 entries, khash
+    buckets with non-singleton keys): the file has the size and sha256 of the one `GDiet_avx -d` wrote for the same reference and
+    command line (tests/golden/rep/mmi.sha256.json, oracle/make_golden.py) -- the other references' p[] arrays are empty"""
+    import hashlib
+    import json
+    exe, d = host_driver
+    want = json.load(open(os.path.join(REP, "mmi.sha256.json")))
+    fq = str(tmp_path / "none.fq")
+    open(fq, "w").write("@r\nACGT\n+\nIIII\n")
+    for tag, kind in (("k19w19", "hifi_rep"), ("k15w10", "ont_rep"), ("k21w11", "sr_rep")):
+        ours = str(tmp_path / (tag + ".mmi"))
+        subprocess.run([exe] + cmd_of(kind) + ["--dump-mmi=" + ours, os.path.join(d, "rep", "ref.fa"), fq], capture_output=True, check=True)
+        data = open(ours, "rb").read()
+        assert len(data) == want[tag]["size"] and hashlib.sha256(data).hexdigest() == want[tag]["sha256"], tag
 
 
 def test_sv_fixtures_reach_concatenation_supplementary_and_secondary_records():

@@ -60,10 +60,27 @@ def test_two_ranks_concatenate_to_the_single_process_sam(kind):
     ps = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
     for p in ps:
         p.start()
-    parts = q.get(timeout=600)
-    for p in ps:
-        p.join(120)
-        assert p.exitcode == 0
+    try:
+        # poll instead of one blocking get: a rank that dies before rank 0 posts the result must fail the test at once, and no worker
+        # may be left behind holding device 0 (a survivor would sit in gather_object for the rest of the session)
+        import queue
+        import time
+        parts, t_end = None, time.time() + 600
+        while parts is None:
+            try:
+                parts = q.get(timeout=2)
+            except queue.Empty:
+                dead = [p.exitcode for p in ps if p.exitcode not in (None, 0)]
+                assert not dead, "a rank exited with %s before the result was posted" % dead
+                assert time.time() < t_end, "no result within 600 s"
+        for p in ps:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.terminate()
+            p.join(30)
     n = len(reads_of(kind))
     assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))  # contiguous, every read once
     assert all(hi > lo for lo, hi, _ in parts)  # both ranks had work
