@@ -8,6 +8,6 @@ The directory name carries a hyphen, so import it with ``importlib`` (see ``test
 ``__graft_entry__.py`` does exactly that.
 """
 from .hip_abi import Context, GdietError, KswScore, library_path, load_library, pack, PRESET_SCORES  # noqa: F401
-from .map_api import Mapper, MapOpt, PRESETS as MAP_PRESETS  # noqa: F401,E402
+from .map_api import Mapper, MapOpt, PRESETS as MAP_PRESETS, map_multi, read_ranges_by_cost_c  # noqa: F401,E402
 from .fastx import FastxReader  # noqa: F401,E402
 from .shard import JobClock, effective_cpus, rank_seed, read_range, read_ranges_by_cost  # noqa: F401,E402

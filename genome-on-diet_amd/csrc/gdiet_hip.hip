@@ -90,6 +90,10 @@ struct gdiet_ctx {
 	int spread = 1;                    // the serial vote kernel runs one read per wavefront (GDIET_SPREAD=0: one per thread)
 	double stage_s[6] = {0, 0, 0, 0, 0, 0};
 	uint64_t last_cells = 0, last_alg_bytes = 0; // of the most recent DP launch
+	// reads the most recent map call gave up on (a DP box outside its read / contig: undefined behaviour in the reference); they come back
+	// with n_regs = 0 while the rest of the batch is mapped.  failed_total: since the context was created.
+	int64_t failed_last = 0, failed_total = 0;
+	std::string warn;                  // what the last such read was (gdiet_hip_map_failed_reads)
 };
 
 #define GD_HIP(call)                                                                              \
@@ -953,6 +957,7 @@ extern "C" int gdiet_hip_ksw_exts2_batch(gdiet_ctx *ctx, int n, const uint8_t *q
 }
 
 #include "map_pipeline.hip.h"
+#include "map_multi.h"
 
 // ---- SURVEY 8f rank 4, chaining half: mg_lchain_dp for a batch of reads (lchain.hip.h on the device, lchain_host.h on host threads) ----
 #include "lchain.hip.h"

@@ -70,6 +70,9 @@ def _bind(lib):
     lib.gdiet_hip_map_batch.argtypes = [vp, vp, C.POINTER(MapOpt), C.c_int, cpp, i32p, i32p, C.POINTER(C.POINTER(Reg))]
     lib.gdiet_hip_free_regs.argtypes = [C.c_int, i32p, C.POINTER(C.POINTER(Reg))]
     lib.gdiet_hip_free_regs.restype = None
+    lib.gdiet_hip_map_batch_multi.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(MapOpt), C.c_int, cpp, i32p, i32p, C.POINTER(C.POINTER(Reg))]
+    lib.gdiet_hip_read_ranges_by_cost.argtypes = [C.c_int, i32p, C.c_int, C.c_int32, i32p]
+    lib.gdiet_hip_map_failed_reads.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]
     lib.gdiet_hip_batch_upload.argtypes = [vp, C.POINTER(vp), C.c_int, cpp, i32p]
     lib.gdiet_hip_map_uploaded.argtypes = [vp, vp, C.POINTER(MapOpt), vp, i32p, C.POINTER(C.POINTER(Reg))]
     lib.gdiet_hip_map_submit.argtypes = [vp, vp, C.POINTER(MapOpt), vp, i32p, C.POINTER(C.POINTER(Reg)), C.POINTER(vp)]
@@ -103,7 +106,40 @@ class MapResult:
             pass
 
 
+def read_ranges_by_cost_c(lens, parts, band=1000):
+    """gdiet_hip_read_ranges_by_cost: the split gdiet_hip_map_batch_multi applies (host arithmetic; shard.read_ranges_by_cost is its mirror)"""
+    lib = load_library()
+    _bind(lib)
+    lens = np.ascontiguousarray(lens, np.int32)
+    bounds = np.zeros(parts + 1, np.int32)
+    rc = lib.gdiet_hip_read_ranges_by_cost(len(lens), lens.ctypes.data_as(C.POINTER(C.c_int32)), parts, band, bounds.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc:
+        raise GdietError("gdiet_hip_read_ranges_by_cost: %d" % rc)
+    return [int(b) for b in bounds]
+
+
+def map_multi(mappers, reads):
+    """gdiet_hip_map_batch_multi: one mini-batch fanned out over the mappers' contexts (one per GPU, index replicated), contiguous read
+    ranges of equal DP cost, records gathered in input order.  The mappers must have been made with the same options."""
+    m0 = mappers[0]
+    n, reads, arr, lens = m0._arrays(reads)
+    k = len(mappers)
+    ctxs = (C.c_void_p * k)(*[m.ctx._h for m in mappers])
+    idxs = (C.c_void_p * k)(*[m._idx for m in mappers])
+    n_regs = (C.c_int32 * n)()
+    regs = (C.POINTER(Reg) * n)()
+    rc = m0.lib.gdiet_hip_map_batch_multi(k, ctxs, idxs, C.byref(m0.opt), n, arr, lens.ctypes.data_as(C.POINTER(C.c_int32)), n_regs, regs)
+    m0.ctx._check(rc)
+    return MapResult(m0.lib, n, n_regs, regs)
+
+
 class Mapper:
+    def failed_reads(self):
+        """(reads the last map call left unmapped because of a degenerate DP box, the same since the context was made, description)"""
+        a, b, w = C.c_int64(), C.c_int64(), C.c_char_p()
+        self.lib.gdiet_hip_map_failed_reads(self.ctx._h, C.byref(a), C.byref(b), C.byref(w))
+        return a.value, b.value, (w.value or b"").decode()
+
     def __init__(self, ctx, names, seqs, preset="hifi", n_threads=0, **overrides):
         self.ctx, self.lib = ctx, load_library()
         _bind(self.lib)

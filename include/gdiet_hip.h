@@ -254,6 +254,27 @@ int gdiet_hip_map_batch(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapo
                         const char *const *seqs, const int32_t *lens, int32_t *n_regs, gdiet_reg_t **regs);
 void gdiet_hip_free_regs(int n_reads, int32_t *n_regs, gdiet_reg_t **regs);
 
+/* Reads of the most recent map call on this context that were given up on and came back unmapped (n_regs = 0) while the rest of their
+ * batch was mapped: a candidate's DP box lay outside its read / contig or had wrapped to an absurd size -- input on which the
+ * reference reads stale heap memory (LR/map.c:1654-1806 with mm_idx_getseq2 returning short / -1), i.e. has no defined result.
+ * last_call / total (since gdiet_hip_init) / what (a one-line description of the last one; valid until the next map call) may be NULL. */
+int gdiet_hip_map_failed_reads(const gdiet_ctx *ctx, int64_t *last_call, int64_t *total, const char **what);
+
+/* ---- single-process multi-GPU fan-out of one mini-batch -----------------------------------------------------------
+ * What step 1 of worker_pipeline calls when the process owns several GPUs (LR/map.c:2132-2137: kt_for over the fragments of the
+ * mini-batch; step 2 prints in input order, LR/kthread.c:97-121): the mini-batch is cut into n_ctx CONTIGUOUS read ranges of equal DP
+ * cost (gdiet_hip_read_ranges_by_cost), range k is mapped by ctxs[k] against idxs[k] (the index replicated per device: build / import
+ * / load it once per context) on a caller thread of its own, and every range writes its records straight into n_regs / regs at its
+ * offset -- the arrays come back exactly as gdiet_hip_map_batch on one context would fill them (same records, same order; release
+ * them with ONE gdiet_hip_free_regs call).  No collective: reads are independent.  Give every context its share of the host's CPUs
+ * first (gdiet_hip_set_host_threads(ctx, gdiet_hip_effective_cpus() / n_ctx)).  Errors are joined: the code of the first failing
+ * range is returned, its text (with device and read range) is gdiet_hip_strerror(ctxs[0]), and no records are handed back. */
+int gdiet_hip_map_batch_multi(int n_ctx, gdiet_ctx *const *ctxs, const gdiet_index *const *idxs, const gdiet_mapopt_t *opt,
+                              int n_reads, const char *const *seqs, const int32_t *lens, int32_t *n_regs, gdiet_reg_t **regs);
+/* bounds[0..n_parts]: contiguous ranges of equal DP cost, a read costing (2 len - 1) * min(band + 1, len) cells (balance by
+ * "sum l_seq^2-ish DP cost, not read count").  Host arithmetic only. */
+int gdiet_hip_read_ranges_by_cost(int n_reads, const int32_t *lens, int n_parts, int32_t band, int32_t *bounds);
+
 /* Two-step form for measurements: stage a batch in HBM once, then map it (repeatedly).  Only the second call belongs
  * to a timed region whose inputs are "already resident in HBM". */
 typedef struct gdiet_read_batch gdiet_read_batch;

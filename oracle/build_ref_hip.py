@@ -21,18 +21,21 @@ OUT = os.path.join(ROOT, "oracle", "_ref")
 LIBDIR = os.path.join(ROOT, "genome-on-diet_amd")
 GLUE = os.path.join(ROOT, "tests", "integration", "gdiet_hip_glue.c")
 DECL = ("int gdiet_glue_enabled(void); void gdiet_glue_index(const mm_idx_t *mi, const mm_mapopt_t *opt); void gdiet_glue_close(void);\n"
-        "void gdiet_glue_map_step(int n_frag, const int *seg_off, const int *n_seg, const mm_bseq1_t *seq, int *n_reg, mm_reg1_t **reg, const mm_mapopt_t *opt);\n")
+        "int gdiet_glue_map_step(int n_frag, const int *seg_off, const int *n_seg, const mm_bseq1_t *seq, int *n_reg, mm_reg1_t **reg, const mm_mapopt_t *opt);\n")
 
 # (file, anchor regex, replacement): the complete reference-side change
 EDITS = [
     # step 1 of worker_pipeline (LR/map.c:2132-2137, SR/map.c:1202-1207): the mini-batch goes to the library instead of kt_for(worker_for)
     ("map.c", r"kt_for\(p->n_threads, worker_for, in, \(\(step_t \*\)in\)->n_frag\);",
-     "{ step_t *gs_ = (step_t *)in; if (gdiet_glue_enabled()) gdiet_glue_map_step(gs_->n_frag, gs_->seg_off, gs_->n_seg, gs_->seq, gs_->n_reg, gs_->reg, p->opt); "
-     "else kt_for(p->n_threads, worker_for, in, gs_->n_frag); }"),
+     "{ step_t *gs_ = (step_t *)in; if (!gdiet_glue_enabled() || gdiet_glue_map_step(gs_->n_frag, gs_->seg_off, gs_->n_seg, gs_->seq, gs_->n_reg, gs_->reg, p->opt)) "
+     "kt_for(p->n_threads, worker_for, in, gs_->n_frag); }"),
     # after mm_mapopt_update (LR/main.c:643): hand the freshly built / loaded index to the library
     ("main.c", r"if \(argc != o\.ind \+ 1\) mm_mapopt_update\(&opt, mi\);",
      "if (argc != o.ind + 1) mm_mapopt_update(&opt, mi);\n\t\tif (gdiet_glue_enabled() && argc != o.ind + 1) gdiet_glue_index(mi, &opt);"),
 ]
+EDITS.append(
+    # before the [PROFILING] lines (LR/main.c:685): contexts and device indexes released, unmapped-by-failure reads reported
+    ("main.c", r"print_profile\(\);", "if (gdiet_glue_enabled()) gdiet_glue_close();\n\tprint_profile();"))
 COMMON = "kthread kalloc misc bseq sdust options index lchain align hit seed format pe esterr splitidx profile".split()
 
 

@@ -189,7 +189,7 @@ int main(int argc, char **argv)
 	// reads are independent: a few worker threads, results printed in input order (the oracle's scalar DP is the slow part)
 	std::vector<std::string> sam_of(qs.size()), trace_of(qs.size());
 	// --stats: reads on which each high-occurrence branch of the seeding stage fires
-	std::atomic<long> st_mzflt{0}, st_mzflt_dropped{0}, st_high{0}, st_over_max{0}, st_heap_replace{0}, st_big_strand{0}, st_max_hits{0}, st_flt_rescued{0};
+	std::atomic<long> st_mzflt{0}, st_mzflt_dropped{0}, st_high{0}, st_over_max{0}, st_heap_replace{0}, st_big_strand{0}, st_max_hits{0}, st_flt_rescued{0}, st_degenerate{0};
 	auto map_one = [&](size_t ri) {
 		std::string out;
 		char *tbuf = nullptr;
@@ -285,6 +285,11 @@ int main(int argc, char **argv)
 				for (unsigned i = 0; i < nc; ++i) C[i].v = vts[i];
 				if (sr_variant) gd_sr_boxes(C, O, R, (uint32_t)len), nc = (unsigned)C.size();
 				else gd_lr_link_and_boxes(C, O, R, (uint32_t)len);
+				if (stats) { // boxes the batch planner of the GPU path refuses (map_pipeline.hip.h: the reference's behaviour is undefined there)
+					bool bad = false;
+					for (unsigned i = 0; i < nc; ++i) bad |= C[i].qlen == 0 || C[i].tlen == 0 || C[i].qlen > (uint32_t)len || C[i].qseq_off + C[i].qlen > (uint32_t)len || C[i].tlen > 8u * (uint32_t)len + 100000u;
+					if (bad) { ++st_degenerate; fprintf(stderr, "[stats] degenerate box in read %s\n", qn[ri].c_str()); }
+				}
 				if (trace && !sr_variant) {
 					fprintf(terr, "AVT n: %u, len: %u\n", nc, (unsigned)len);
 					for (unsigned i = 0; i < nc; ++i) {
@@ -356,8 +361,8 @@ int main(int argc, char **argv)
 			}
 		fprintf(stderr, "[stats] index: keys=%llu multi=%llu keys>mid_occ(%d)=%llu keys>max_max_occ(%d)=%llu max_count=%llu\n", (unsigned long long)I.n_keys, (unsigned long long)multi,
 		        O.mid_occ, (unsigned long long)over_mid, O.max_max_occ, (unsigned long long)over_max, (unsigned long long)max_cnt);
-		fprintf(stderr, "[stats] reads=%zu mz_flt_drops=%ld (minimizers dropped %ld) high_occ_streak=%ld rescue=%ld heap_replace=%ld over_max_max_occ=%ld strand>4096hits=%ld max_strand_hits=%ld\n",
-		        qs.size(), st_mzflt.load(), st_mzflt_dropped.load(), st_high.load(), st_flt_rescued.load(), st_heap_replace.load(), st_over_max.load(), st_big_strand.load(), st_max_hits.load());
+		fprintf(stderr, "[stats] reads=%zu mz_flt_drops=%ld (minimizers dropped %ld) high_occ_streak=%ld rescue=%ld heap_replace=%ld over_max_max_occ=%ld strand>4096hits=%ld max_strand_hits=%ld degenerate_box_reads=%ld\n",
+		        qs.size(), st_mzflt.load(), st_mzflt_dropped.load(), st_high.load(), st_flt_rescued.load(), st_heap_replace.load(), st_over_max.load(), st_big_strand.load(), st_max_hits.load(), st_degenerate.load());
 	}
 	for (size_t ri = 0; ri < qs.size(); ++ri) {
 		fputs(trace_of[ri].c_str(), stderr);

@@ -4,6 +4,10 @@
  * result against the library with -Wl,--no-undefined -> oracle/_ref/gdiet_lr_hip.  With GDIET_HIP=1 in the environment that
  * binary runs the reference's own main(), reader and mm_write_sam3 around this library's per-read path; without it, it is GDiet_avx.
  *
+ * GDIET_HIP_DEVICES=0,1,2,3 (default "0"): the HIP devices the process maps on -- one context and one copy of the index per entry, every
+ * mini-batch cut into contiguous read ranges of equal DP cost (gdiet_hip_map_batch_multi).  A device may be listed
+ * twice (two contexts on one GPU: how the one-GPU test box exercises the fan-out).
+ *
  *   main.c, after mm_mapopt_update():   if (gdiet_glue_enabled()) gdiet_glue_index(mi, &opt);
  *   map.c, step 1 of worker_pipeline:   if (gdiet_glue_enabled()) gdiet_glue_map_step(s->n_frag, s->seg_off, s->n_seg, s->seq, s->n_reg, s->reg, p->opt);
  *                                       else kt_for(p->n_threads, worker_for, in, s->n_frag);          (LR/map.c:2132-2137)
@@ -29,8 +33,15 @@ typedef struct mm_idx_bucket_s {
 	void *h;
 } mm_idx_bucket_t;
 
-static gdiet_ctx *g_ctx;
-static gdiet_index *g_idx;
+#define GLUE_MAX_DEV 16
+static gdiet_ctx *g_ctx[GLUE_MAX_DEV];
+static gdiet_index *g_idx[GLUE_MAX_DEV];
+static int g_n;
+static long long g_failed_reads;
+
+#ifdef PROFILE
+#include "profile.h" /* the reference's [PROFILING] counters (LR/profile.h:10-21), fed from the library's stage clocks below */
+#endif
 
 int gdiet_glue_enabled(void)
 {
@@ -44,18 +55,45 @@ int gdiet_glue_enabled(void)
 
 static void die(const char *what)
 {
-	fprintf(stderr, "[gdiet_hip] %s: %s\n", what, g_ctx ? gdiet_hip_strerror(g_ctx) : "no context");
-	exit(1); /* no CPU fallback once the GPU path was asked for */
+	fprintf(stderr, "[gdiet_hip] %s: %s\n", what, g_ctx[0] ? gdiet_hip_strerror(g_ctx[0]) : "no context");
+	exit(1); /* set-up failures only (no device, no memory for the index): no CPU fallback once the GPU path was asked for */
+}
+
+static void glue_open(void)
+{
+	const char *e = getenv("GDIET_HIP_DEVICES");
+	int dev[GLUE_MAX_DEV], n = 0, k;
+	if (g_n) return;
+	if (e && *e) {
+		char *end;
+		while (*e && n < GLUE_MAX_DEV) {
+			dev[n++] = (int)strtol(e, &end, 10);
+			if (end == e) { fprintf(stderr, "[gdiet_hip] GDIET_HIP_DEVICES: cannot parse '%s'\n", e); exit(1); }
+			e = *end == ',' ? end + 1 : end;
+		}
+	}
+	if (n == 0) dev[n++] = 0;
+	for (k = 0; k < n; ++k)
+		if (gdiet_hip_init(&g_ctx[k], dev[k])) {
+			fprintf(stderr, "[gdiet_hip] gdiet_hip_init(device %d): is there a gfx950 device?\n", dev[k]);
+			exit(1);
+		}
+	g_n = n;
+	if (n > 1) { /* the contexts share the host's CPUs */
+		int t = gdiet_hip_effective_cpus() / n;
+		for (k = 0; k < n; ++k) gdiet_hip_set_host_threads(g_ctx[k], t > 1 ? t : 1);
+	}
 }
 
 /* mm_idx_t -> gdiet_hip_index_import: walk the buckets' hash tables (LR/index.c:84-100 is the lookup this inverts) */
 void gdiet_glue_index(const mm_idx_t *mi, const mm_mapopt_t *opt)
 {
 	uint64_t n_keys = 0, n_pos = 0, j = 0, o = 0;
-	int b;
+	int b, d;
 	uint32_t i;
-	if (!g_ctx && gdiet_hip_init(&g_ctx, 0)) die("gdiet_hip_init (is there a gfx950 device?)");
-	if (g_idx) gdiet_hip_index_destroy(g_ctx, g_idx), g_idx = 0;
+	glue_open();
+	for (d = 0; d < g_n; ++d)
+		if (g_idx[d]) gdiet_hip_index_destroy(g_ctx[d], g_idx[d]), g_idx[d] = 0;
 	for (b = 0; b < 1 << mi->b; ++b) {
 		idxhash_t *h = (idxhash_t *)mi->B[b].h;
 		khint_t k;
@@ -87,9 +125,12 @@ void gdiet_glue_index(const mm_idx_t *mi, const mm_mapopt_t *opt)
 				}
 		}
 		for (i = 0; i < mi->n_seq; ++i) names[i] = mi->seq[i].name, lens[i] = mi->seq[i].len, offs[i] = mi->seq[i].offset;
-		if (gdiet_hip_index_import(g_ctx, &g_idx, mi->k, mi->w, opt->pattern, opt->pattern_len, (int)mi->n_seq, names, lens, offs, mi->S, n_keys, keys,
-		                           cnt, pos))
-			die("gdiet_hip_index_import");
+		for (d = 0; d < g_n; ++d) /* the index is replicated: one device copy per context */
+			if (gdiet_hip_index_import(g_ctx[d], &g_idx[d], mi->k, mi->w, opt->pattern, opt->pattern_len, (int)mi->n_seq, names, lens, offs, mi->S, n_keys,
+			                           keys, cnt, pos)) {
+				fprintf(stderr, "[gdiet_hip] gdiet_hip_index_import (context %d): %s\n", d, gdiet_hip_strerror(g_ctx[d]));
+				exit(1);
+			}
 		free(keys), free(pos), free(cnt), free((void *)names), free(lens), free(offs);
 	}
 }
@@ -114,8 +155,10 @@ static gdiet_mapopt_t glue_opt(const mm_mapopt_t *o)
 }
 
 /* step 1 of worker_pipeline for one mini-batch: fills n_reg[] / reg[] exactly as kt_for(worker_for) does (libc allocations that
- * step 2 frees: LR/map.c:2163-2167) */
-void gdiet_glue_map_step(int n_frag, const int *seg_off, const int *n_seg, const mm_bseq1_t *seq, int *n_reg, mm_reg1_t **reg, const mm_mapopt_t *opt)
+ * step 2 frees: LR/map.c:2163-2167).  Returns 0, or non-zero when the library could not map the batch: the caller then runs
+ * kt_for(worker_for) on it -- the reference's own path -- and the run goes on ("shim returns non-zero => caller falls back
+ * to CPU path"); a read the library gave up on (degenerate DP box) comes back unmapped and is counted. */
+int gdiet_glue_map_step(int n_frag, const int *seg_off, const int *n_seg, const mm_bseq1_t *seq, int *n_reg, mm_reg1_t **reg, const mm_mapopt_t *opt)
 {
 	int i, j;
 	const char **seqs = (const char **)malloc(sizeof(char *) * (n_frag + 1));
@@ -124,7 +167,32 @@ void gdiet_glue_map_step(int n_frag, const int *seg_off, const int *n_seg, const
 	gdiet_mapopt_t go = glue_opt(opt);
 	(void)n_seg; /* single-segment reads: the path maps segment 0 of every fragment, as mm_map_frag does (SURVEY bug-compat item 7) */
 	for (i = 0; i < n_frag; ++i) seqs[i] = seq[seg_off[i]].seq, lens[i] = seq[seg_off[i]].l_seq;
-	if (gdiet_hip_map_batch(g_ctx, g_idx, &go, n_frag, seqs, lens, n_regs, regs)) die("gdiet_hip_map_batch");
+	if (gdiet_hip_map_batch_multi(g_n, g_ctx, (const gdiet_index *const *)g_idx, &go, n_frag, seqs, lens, n_regs, regs)) {
+		fprintf(stderr, "[gdiet_hip] gdiet_hip_map_batch_multi failed for a mini-batch of %d reads (%s): mapping it with the reference's worker_for\n", n_frag,
+		        gdiet_hip_strerror(g_ctx[0]));
+		free(regs), free(n_regs), free(lens), free((void *)seqs);
+		return 1;
+	}
+	{
+		long long last = 0;
+		const char *what = 0;
+		gdiet_hip_map_failed_reads(g_ctx[0], (int64_t *)&last, 0, &what);
+		if (last) g_failed_reads += last, fprintf(stderr, "[gdiet_hip] %s\n", what);
+	}
+#ifdef PROFILE
+	{ /* [PROFILING] lines (LR/profile.h:10-21, LR/main.c:685): the counters are nanoseconds summed over worker threads in the reference; the
+	   * GPU path has one clock per stage and mini-batch: seed kernel (sketch2 + get_shift + sketch3 + filter + lookup; the pattern
+	   * alignment is part of that kernel and is not timed apart), vote kernel, gather + DP + backtrack (+ the host stages around them) */
+		int d;
+		for (d = 0; d < g_n; ++d) {
+			double st[6];
+			if (gdiet_hip_map_stage_seconds(g_ctx[d], st)) continue;
+			atomic_fetch_add(&pf_seeding, (uint_least64_t)(st[0] * 1e9));
+			atomic_fetch_add(&pf_voting, (uint_least64_t)(st[1] * 1e9));
+			atomic_fetch_add(&pf_sequence_alignment, (uint_least64_t)((st[2] + st[3] + st[4]) * 1e9));
+		}
+	}
+#endif
 	for (i = 0; i < n_frag; ++i) {
 		const int off = seg_off[i];
 		n_reg[off] = n_regs[i];
@@ -145,10 +213,16 @@ void gdiet_glue_map_step(int n_frag, const int *seg_off, const int *n_seg, const
 	}
 	gdiet_hip_free_regs(n_frag, n_regs, regs);
 	free(regs), free(n_regs), free(lens), free((void *)seqs);
+	return 0;
 }
 
 void gdiet_glue_close(void)
 {
-	if (g_idx) gdiet_hip_index_destroy(g_ctx, g_idx), g_idx = 0;
-	if (g_ctx) gdiet_hip_destroy(g_ctx), g_ctx = 0;
+	int d;
+	if (g_failed_reads) fprintf(stderr, "[gdiet_hip] %lld read(s) left unmapped by the GPU path (degenerate DP boxes)\n", g_failed_reads);
+	for (d = 0; d < g_n; ++d) {
+		if (g_idx[d]) gdiet_hip_index_destroy(g_ctx[d], g_idx[d]), g_idx[d] = 0;
+		if (g_ctx[d]) gdiet_hip_destroy(g_ctx[d]), g_ctx[d] = 0;
+	}
+	g_n = 0;
 }

@@ -89,3 +89,39 @@ def test_patched_reference_binary_prints_the_golden_paf(kind, tmp_path):
     r = subprocess.run([exe, "-t", "4"] + paf_cmd_of(kind) + [ref_fa, fq], capture_output=True, text=True, env=dict(os.environ, GDIET_HIP="1"), timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.rstrip("\n").split("\n") == golden_paf(kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["hifi_sv", "sr"])
+def test_patched_reference_binary_fans_out_over_two_contexts(kind, tmp_path):
+    """GDIET_HIP_DEVICES=0,0: the reference's one-process CLI with TWO contexts (here both on the test box's one device), every
+    mini-batch cut into two read ranges by gdiet_hip_map_batch_multi -- the golden SAM, and [PROFILING] lines fed from the library's
+    stage clocks (LR/profile.h:10-21)"""
+    variant = "sr" if SETS[kind][2] == "sr" else "lr"
+    exe = HIP_BIN[variant]
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/gdiet_%s_hip not built (needs /root/reference at build time)" % variant)
+    ref_fa, fq = _inputs(kind, tmp_path)
+    r = subprocess.run([exe, "-t", "4"] + cmd_of(kind) + [ref_fa, fq], capture_output=True, text=True,
+                       env=dict(os.environ, GDIET_HIP="1", GDIET_HIP_DEVICES="0,0"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _body(r.stdout) == golden_sam(kind)
+    prof = {l.split(":")[0]: int(l.split(":")[1].split()[0]) for l in r.stderr.split("\n") if l.startswith("[PROFILING]")}
+    assert prof["[PROFILING] seeding time"] > 0 and prof["[PROFILING] voting time"] > 0 and prof["[PROFILING] sequence alignment time"] > 0
+
+
+@pytest.mark.gpu
+def test_patched_reference_binary_survives_a_degenerate_box(tmp_path):
+    """the glue reports a read the library gave up on and goes on: every other read keeps its golden records (GDIET_FAULT_BOX)"""
+    exe = HIP_BIN["lr"]
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/gdiet_lr_hip not built")
+    ref_fa, fq = _inputs("hifi", tmp_path)
+    r = subprocess.run([exe, "-t", "4"] + cmd_of("hifi") + [ref_fa, fq], capture_output=True, text=True,
+                       env=dict(os.environ, GDIET_HIP="1", GDIET_FAULT_BOX="3"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    victim = reads_of("hifi")[3][0]
+    got = _body(r.stdout)
+    assert [l for l in got if l.split("\t")[0] != victim] == [l for l in golden_sam("hifi") if l.split("\t")[0] != victim]
+    assert [l.split("\t")[1] for l in got if l.split("\t")[0] == victim] == ["4"]
+    assert "degenerate DP box" in r.stderr

@@ -432,3 +432,75 @@ def test_file_to_sam_failure_does_not_hang(gpu_ctx, pkg, tmp_path):
         assert n == 2000 and open(out).read() == "".join(l + "\n" for l in golden_sam("sr"))
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("kind,n_ctx", [("hifi_sv", 2), ("sr", 2), ("hifi_rep", 3)])
+def test_single_process_fan_out_over_contexts(pkg, kind, n_ctx):
+    """gdiet_hip_map_batch_multi (one process, one context per GPU, the mini-batch cut into contiguous ranges of equal DP
+    cost, records gathered in input order): n_ctx contexts on the one device of the test box, each with its own copy of the index;
+    the records are the golden SAM, byte for byte, exactly as from one context"""
+    import torch  # noqa: F401
+    base, stem, preset = SETS[kind]
+    names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+    reads = reads_of(kind)
+    ctxs = [pkg.Context(0) for _ in range(n_ctx)]
+    ms = [pkg.Mapper(c, names, seqs, preset=preset, **OVERRIDES.get(kind, {})) for c in ctxs]
+    try:
+        for m in ms:
+            m.set_host_threads(max(1, pkg.effective_cpus() // n_ctx))
+        res = pkg.map_multi(ms, [r[1] for r in reads])
+        assert ms[0].sam_batch(res, reads) == "".join(l + "\n" for l in golden_sam(kind))
+        bounds = pkg.read_ranges_by_cost_c([len(r[1]) for r in reads], n_ctx, band=1000 if preset != "sr" else 150)
+        assert all(hi > lo for lo, hi in zip(bounds, bounds[1:]))  # every context had work
+        del res
+        # errors are joined: a bad option fails the call with a text that names the context, and hands nothing back
+        bad = pkg.MapOpt.from_buffer_copy(ms[0].opt)
+        ms[0].opt, keep = bad, ms[0].opt
+        ms[0].opt.q2 = 120
+        with pytest.raises(pkg.GdietError):
+            pkg.map_multi(ms, [r[1] for r in reads[:8]])
+        ms[0].opt = keep
+    finally:
+        for m in ms:
+            m.close()
+        for c in ctxs:
+            c.close()
+
+
+def test_degenerate_box_fails_its_read_not_the_batch(pkg, monkeypatch):
+    """a read whose DP box is degenerate (fault injection, GDIET_FAULT_BOX=<read index>: no read built so far produces one) comes
+    back unmapped and is counted; every other read of the batch gets its golden records -- synchronously and with batches in flight"""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+from conftest import load_pkg
+from fixture_io import LR, golden_sam, read_fasta, read_fastq
+pkg = load_pkg()
+ctx = pkg.Context(0)
+names, seqs = read_fasta(os.path.join(LR, "ref.fa.gz"))
+reads = read_fastq(os.path.join(LR, "hifi.fq.gz"))
+m = pkg.Mapper(ctx, names, seqs, preset="hifi")
+victim = reads[5][0]
+want = [l for l in golden_sam("hifi") if l.split("	")[0] != victim]
+def check(res):
+    lines = [l for l in m.sam_batch(res, reads).split("
+") if l]
+    mine = [l for l in lines if l.split("	")[0] == victim]
+    assert len(mine) == 1 and mine[0].split("	")[1] == "4", mine[:1]
+    assert [l for l in lines if l.split("	")[0] != victim] == want
+    last, total, what = m.failed_reads()
+    assert last == 1 and "degenerate DP box" in what, (last, what)
+check(m.map([r[1] for r in reads]))
+b = m.upload([r[1] for r in reads])
+t = m.submit(b)
+check(m.wait(t))
+assert m.failed_reads()[1] == 2
+m.free_batch(b); m.close(); ctx.close()
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GDIET_FAULT_BOX="5")  # read when the library first maps: a process of its own
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -93,3 +93,21 @@ def test_effective_cpus_respects_quota_and_affinity():
     assert n <= len(os.sched_getaffinity(0))
     lib = pkg.load_library()
     assert lib.gdiet_hip_effective_cpus() == n
+
+
+def test_c_read_ranges_equal_the_python_mirror():
+    """gdiet_hip_read_ranges_by_cost (what gdiet_hip_map_batch_multi cuts a mini-batch with; host arithmetic, callable without a GPU)
+    against shard.read_ranges_by_cost: the same boundaries for HiFi-, ONT- and short-read-like length mixes, 1..8 parts, empty input"""
+    import numpy as np
+    from conftest import load_pkg
+    pkg = load_pkg()
+    rng = np.random.default_rng(3)
+    cases = [np.clip(rng.normal(15000, 2000, 5120), 5000, 25000).astype(np.int32), np.clip(rng.lognormal(np.log(50000), 0.35, 700), 5000, 150000).astype(np.int32),
+             np.full(4096, 150, np.int32), rng.integers(0, 400, 333).astype(np.int32), np.zeros(0, np.int32), np.array([7], np.int32)]
+    for lens in cases:
+        for parts in (1, 2, 3, 4, 8):
+            for band in (150, 1000, 1300):
+                want = pkg.read_ranges_by_cost(lens, parts, band=band)
+                got = pkg.read_ranges_by_cost_c(lens, parts, band=band)
+                assert got == [int(x) for x in want], (len(lens), parts, band)
+                assert got[0] == 0 and got[-1] == len(lens) and all(a <= b for a, b in zip(got, got[1:]))
