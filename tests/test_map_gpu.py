@@ -467,40 +467,12 @@ def test_single_process_fan_out_over_contexts(pkg, kind, n_ctx):
             c.close()
 
 
-def test_degenerate_box_fails_its_read_not_the_batch(pkg, monkeypatch):
+def test_degenerate_box_fails_its_read_not_the_batch():
     """a read whose DP box is degenerate (fault injection, GDIET_FAULT_BOX=<read index>: no read built so far produces one) comes
-    back unmapped and is counted; every other read of the batch gets its golden records -- synchronously and with batches in flight"""
+    back unmapped and is counted; every other read of the batch gets its golden records -- synchronously and with a batch in flight
+    (tests/fault_box_check.py, in a process of its own: the library reads the variable once)"""
     import subprocess
     import sys
-    code = r"""
-import os, sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import torch
-from conftest import load_pkg
-from fixture_io import LR, golden_sam, read_fasta, read_fastq
-pkg = load_pkg()
-ctx = pkg.Context(0)
-names, seqs = read_fasta(os.path.join(LR, "ref.fa.gz"))
-reads = read_fastq(os.path.join(LR, "hifi.fq.gz"))
-m = pkg.Mapper(ctx, names, seqs, preset="hifi")
-victim = reads[5][0]
-want = [l for l in golden_sam("hifi") if l.split("	")[0] != victim]
-def check(res):
-    lines = [l for l in m.sam_batch(res, reads).split("
-") if l]
-    mine = [l for l in lines if l.split("	")[0] == victim]
-    assert len(mine) == 1 and mine[0].split("	")[1] == "4", mine[:1]
-    assert [l for l in lines if l.split("	")[0] != victim] == want
-    last, total, what = m.failed_reads()
-    assert last == 1 and "degenerate DP box" in what, (last, what)
-check(m.map([r[1] for r in reads]))
-b = m.upload([r[1] for r in reads])
-t = m.submit(b)
-check(m.wait(t))
-assert m.failed_reads()[1] == 2
-m.free_batch(b); m.close(); ctx.close()
-print("ok")
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GDIET_FAULT_BOX="5")  # read when the library first maps: a process of its own
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fault_box_check.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, env=dict(os.environ, GDIET_FAULT_BOX="5"), timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
