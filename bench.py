@@ -505,6 +505,10 @@ def main():
         cells_launch = float(cells.mean())
         # per-cell figures from the PMC passes of this very command (tools/pmc_traffic.py, tools/pmc_valu.py -> profiles/*.json)
         traffic, traffic_src, valu = None, None, {}
+        try:
+            sclk = ctx.last_dp_clock()  # (median MHz, min MHz, median wavefront ms) over the wavefronts of the last DP launches
+        except Exception:
+            sclk = None
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
             try:
                 t = json.load(open(f))
@@ -519,13 +523,19 @@ def main():
                 if "valu_insts_per_cell" in t:
                     insts = t["valu_insts_per_cell"] * cells_launch
                     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32; 1024 SIMDs at 2.4 GHz
+                    # cycles per VALU instruction at the clock the kernel's own wavefronts measured (s_memtime / s_memrealtime stamps)
+                    cyc = dp * 1e-3 * sclk[0] * 1e6 / (insts / 1024.0) if sclk else None
                     valu = {"valu_insts_per_cell": t["valu_insts_per_cell"], "salu_insts_per_cell": t.get("salu_insts_per_cell"),
                             "valu_insts_per_1024_cell_row": 1024 * t["valu_insts_per_cell"],
-                            "valu_util": insts * 2.0 / (1024 * 2.4e9 * dp * 1e-3),
-                            "valu_util_note": "PMC SQ_INSTS_VALU of this kernel per cell (%s) x this run's cells per launch x 2 cycles (SIMD-32 issue peak, "
-                                              "MI355X_MICROARCH.md) / (1024 SIMDs x 2.4 GHz x this run's kernel time); measured issue cost of the kernel's "
-                                              "packed-16 instruction mix: ~4.2 cycles (profiles/r02_valu_issue.md), against which the kernel is at ~93 %%"
-                                              % os.path.relpath(f, ROOT),
+                            "sclk_cycles_per_valu_inst": cyc,
+                            # profiles/r03_clock.md: a pure stream of the kernel's instruction class (v_pk_add/sub/max/min_*16, v_perm, v_bfi) issues at
+                            # 4.30 (8 wavefronts per SIMD) .. 4.47 (5 per SIMD) shader cycles per wave-instruction per SIMD: the hardware's rate
+                            "valu_issue_frac": (4.47 / cyc) if cyc else None,
+                            "valu_util": insts * 2.0 / (1024 * (sclk[0] * 1e6 if sclk else 2.4e9) * dp * 1e-3),
+                            "valu_util_note": "PMC SQ_INSTS_VALU of this kernel per cell (%s) x this run's cells per launch; sclk_cycles_per_valu_inst = kernel time x "
+                                              "measured sclk / instructions per SIMD; valu_issue_frac = 4.47 cycles (pure stream of the same instruction class at 5 "
+                                              "wavefronts per SIMD, tools/clock_probe.hip) / that; valu_util = against 2 cycles per wave64 instruction (SIMD-32 issue "
+                                              "peak of MI355X_MICROARCH.md, which this class of instructions does not reach)" % os.path.relpath(f, ROOT),
                             "simd_cycles_per_valu_inst_pmc": t.get("simd_cycles_per_valu_inst"), "valu_active_frac_pmc": t.get("valu_active_frac")}
                     break
             except Exception:
@@ -569,7 +579,10 @@ def main():
                               "gcups": cells.sum() / (dp_ms.sum() * 1e-3) / 1e9, "kernel_ms": dp,
                               "kernel_ms_note": "mean over the K timed launches (HIP events on each launch's stream); the 64-lane kernel walks its own "
                                                 "alignments back, so this is DP + backtrack; the other batches' seeding/voting kernels share the GPU",
-                              "kernel_ms_alone": dp_alone, "backtrack_kernel_ms": bt}, **valu),
+                              "kernel_ms_alone": dp_alone, "backtrack_kernel_ms": bt,
+                              "sclk_mhz": sclk[0] if sclk else None, "sclk_mhz_min": sclk[1] if sclk else None,
+                              "sclk_note": "shader clock the DP kernel sustained: per wavefront ticks(s_memtime) / ticks(s_memrealtime) x 100 MHz around its DP rows, "
+                                           "median / minimum over the wavefronts (gdiet_hip_last_dp_clock); 2 400 MHz is the part's peak: not throttled"}, **valu),
         }
         # N ranks share the node's CPUs: the host stages of a step must stay hidden behind its DP kernel
         if st[2] + st[4] > 0.8 * dp * 1e-3:

@@ -272,6 +272,36 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	delete ctx;
 }
 
+#ifdef GD_CLOCK_STAMP
+// measurement build only (tools/clock_probe.py; not declared in include/gdiet_hip.h): the raw per-wavefront stamps
+extern "C" int gdiet_hip_debug_clock_stamps(unsigned long long *out, int n_slots)
+{
+	if (n_slots > GD_CLOCK_SLOTS) n_slots = GD_CLOCK_SLOTS;
+	return hipMemcpyFromSymbol(out, HIP_SYMBOL(gd_clock_stamps), sizeof(unsigned long long) * 4 * (size_t)n_slots) == hipSuccess ? n_slots : -1;
+}
+#endif
+// the clock stamps of the 64-lane DP kernel's wavefronts (ksw_wave.hip.h), reduced: per wavefront sclk = ticks(s_memtime) /
+// ticks(s_memrealtime) x 100 MHz.  Call after the batch has completed.
+extern "C" int gdiet_hip_last_dp_clock(gdiet_ctx *ctx, double *sclk_mhz_median, double *sclk_mhz_min, double *wavefront_ms_median)
+{
+	if (!ctx) return GDIET_E_PARAM;
+	(void)hipSetDevice(ctx->device);
+	std::vector<unsigned long long> st((size_t)GD_CLOCK_SLOTS * 4);
+	GD_HIP(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(gd_clock_stamps), sizeof(unsigned long long) * st.size()));
+	std::vector<double> f, ms;
+	for (int i = 0; i < GD_CLOCK_SLOTS; ++i) {
+		const unsigned long long mt0 = st[4 * i], rt0 = st[4 * i + 1], mt1 = st[4 * i + 2], rt1 = st[4 * i + 3];
+		if (rt1 > rt0 && mt1 > mt0 && rt1 - rt0 > 1000) f.push_back((double)(mt1 - mt0) / (double)(rt1 - rt0) * 100.0), ms.push_back((double)(rt1 - rt0) * 1e-5); // (>= 10 us)
+	}
+	if (f.empty()) { ctx->err = "no 64-lane DP kernel has run yet"; return GDIET_E_PARAM; }
+	std::sort(f.begin(), f.end()), std::sort(ms.begin(), ms.end());
+	if (sclk_mhz_median) *sclk_mhz_median = f[f.size() / 2];
+	if (sclk_mhz_min) *sclk_mhz_min = f.front();
+	if (wavefront_ms_median) *wavefront_ms_median = ms[ms.size() / 2];
+	return GDIET_OK;
+}
+
+
 extern "C" const char *gdiet_hip_strerror(const gdiet_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
 extern "C" int gdiet_hip_device_name(const gdiet_ctx *ctx, char *buf, size_t len)

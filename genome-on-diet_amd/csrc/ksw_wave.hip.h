@@ -79,6 +79,12 @@ static inline bool gd_wave_supported(int qlen, int tlen, int w, int lanes)
 // TAG only names the launch (0: a whole batch; 1 / 2: the head / tail launch of a split batch, see gdiet_hip.hip) so that a
 // profile lists them apart.
 // DUAL = false is the single-affine (ksw_extz2) form of the same kernel: see gdw_compute.
+// Every wavefront of the 64-lane kernel stamps s_memtime (the shader clock) and s_memrealtime (the constant 100 MHz reference) around its
+// DP rows -- four scalar stores per wavefront, nothing kept in registers in between -- so that the clock the kernel really sustained can be
+// reported beside its duration (gdiet_hip_last_dp_clock; bench.py roofline.sclk_mhz; profiles/r03_clock.md).  The table is shared by
+// the contexts of a process: with several DP kernels in flight the stamps of a slot are those of whichever wrote last; any of them do.
+#define GD_CLOCK_SLOTS 16384
+__device__ unsigned long long gd_clock_stamps[GD_CLOCK_SLOTS * 4];
 template <int LANES, int TAG = 0, bool DUAL = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LANES == 64 ? 5 : 4))) // 64-lane form: 5 wavefronts per SIMD = at most 96 VGPRs
 void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
@@ -107,6 +113,8 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 		if (!__builtin_amdgcn_ballot_w64(live)) return;
 	}
 	const KswTask *Tp = tasks + tid;
+	// (clock stamps, indexed by the task id -- live to the end of the kernel anyway -- so that the row loop carries nothing for them)
+	if (LANES == 64 && lane == 0) gd_clock_stamps[(tid & (GD_CLOCK_SLOTS - 1)) * 4] = __builtin_amdgcn_s_memtime(), gd_clock_stamps[(tid & (GD_CLOCK_SLOTS - 1)) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 	const int qlen = __builtin_amdgcn_readfirstlane(Tp->qlen), tlen = __builtin_amdgcn_readfirstlane(Tp->tlen);
 	int w = __builtin_amdgcn_readfirstlane(Tp->w);
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
@@ -263,6 +271,8 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 	// The 64-lane form (one alignment per wavefront) walks its own alignment back right away when given the CIGAR buffers: the
 	// walk is latency-bound and overlaps the DP of the other resident wavefronts, instead of a separate pass after the last one.
 	const bool fuse = LANES == 64 && cigar != nullptr;
+	if (LANES == 64 && lane == 0) // (the DP rows only: the walk below is latency-bound)
+		gd_clock_stamps[(tid & (GD_CLOCK_SLOTS - 1)) * 4 + 2] = __builtin_amdgcn_s_memtime(), gd_clock_stamps[(tid & (GD_CLOCK_SLOTS - 1)) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 	if (L.blk == mlast && live) {
 		score_out[tid] = Rf >> 3;
 		status[tid] = fuse ? GD_ST_TRACED : GD_ST_DONE;

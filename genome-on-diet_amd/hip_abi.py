@@ -135,6 +135,13 @@ class Context:
         self._check(self.lib.gdiet_hip_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_dp_clock(self):
+        """(median sclk MHz, min sclk MHz, median wavefront ms) of the 64-lane DP kernel's wavefronts (gdiet_hip_last_dp_clock)"""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.lib.gdiet_hip_last_dp_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        self._check(self.lib.gdiet_hip_last_dp_clock(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def last_dp_work(self):
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self.lib.gdiet_hip_last_dp_work(self._h, C.byref(a), C.byref(b)))

@@ -170,6 +170,10 @@ int gdiet_hip_set_dp_split(gdiet_ctx *ctx, int on);
 /* average device time (ms, HIP events on the launch stream) of the DP kernel(s) and of the backtrack kernel of the
  * most recent *_dev / host batch; only valid after the stream has been synchronised. */
 int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *backtrack_ms);
+/* The shader clock the 64-lane DP kernel sustained, from its own wavefronts: each stamps s_memtime (shader clock) and s_memrealtime
+ * (constant 100 MHz) around its DP rows.  Median and minimum over the wavefronts of the most recent launches of the process, and the
+ * median duration of one wavefront's rows.  (Says whether the kernel ran throttled: profiles/r03_clock.md.) */
+int gdiet_hip_last_dp_clock(gdiet_ctx *ctx, double *sclk_mhz_median, double *sclk_mhz_min, double *wavefront_ms_median);
 /* work of the most recent DP launch: DP cells = sum (qlen+tlen-1)*min(w+1,qlen,tlen), and the algorithmic bytes of
  * SURVEY.md 8d = cells + (qlen+tlen) + qlen + ceil(tlen/2) per alignment (what bench.py's roofline divides by the kernel time) */
 int gdiet_hip_last_dp_work(const gdiet_ctx *ctx, uint64_t *cells, uint64_t *alg_bytes);
