@@ -695,6 +695,10 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			// else while they run): the device-to-host copies below are kernels of the runtime and would start only when DP wavefronts of
 			// the NEXT batch retire -- ~1 s for 400 KB, and that second is part of the lane's cycle (kernel trace of the ONT path, round 2).
 			// map_post_kernel starts in the gap between the two DP kernels, so it writes the results to page-locked host memory itself.
+			// long alignments: one wavefront per alignment (mm_fix_cigar on lane 0, the walk over the bases by all lanes: 22 -> ~2 ms per HiFi
+			// batch); short reads keep one alignment per thread (hundreds of thousands of 150-base walks).  GDIET_POST_WAVE=0 / 1 forces one.
+			static const char *pw_env = getenv("GDIET_POST_WAVE");
+			const bool post_wave = pw_env ? atoi(pw_env) != 0 : coff[nb] / std::max(nb, 1) >= 2000;
 			const bool xport = (ctx->last_mask & 8) != 0 && !no_export;
 			if (xport) {
 				const size_t need = sizeof(GdPostOut) * (size_t)nb + sizeof(int32_t) * 2 * nbp + 256;
@@ -708,12 +712,17 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			if (xport && ctx->h_pin.p) {
 				int32_t *x_score = (int32_t *)ctx->h_pin.p, *x_ncig = x_score + nbp;
 				GdPostOut *x_post = (GdPostOut *)(x_ncig + nbp);
-				hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+				if (post_wave) hipLaunchKernelGGL(map_post_wave_kernel, dim3(nb), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+				                                  (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, x_post, x_score, x_ncig);
+				else hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
 				                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, x_post, x_score, x_ncig);
 				h_score = x_score, h_ncig = x_ncig, h_post = x_post;
 				exported = true;
 			} else {
-				hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+				if (post_wave) hipLaunchKernelGGL(map_post_wave_kernel, dim3(nb), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+				                                  (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p,
+				                                  (int32_t *)nullptr, (int32_t *)nullptr);
+				else hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
 				                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p,
 				                   (int32_t *)nullptr, (int32_t *)nullptr);
 				GD_HIP(hipMemcpyAsync(ctx->h_post.p, ctx->m_post.p, sizeof(GdPostOut) * (size_t)nb, hipMemcpyDeviceToHost, sd));

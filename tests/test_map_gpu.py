@@ -476,3 +476,15 @@ def test_degenerate_box_fails_its_read_not_the_batch():
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fault_box_check.py")
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, env=dict(os.environ, GDIET_FAULT_BOX="5"), timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("env,kinds", [({"GDIET_POST_WAVE": "0"}, ["hifi_sv", "ont_sv", "hifi_rep"]),  # long alignments through the one-thread-per-alignment P1 kernel
+                                       ({"GDIET_POST_WAVE": "1"}, ["sr", "sr_var", "sr_edge", "hifi_edge"])])  # short ones through the wave-parallel form
+def test_golden_sam_under_the_other_post_kernel(env, kinds):
+    """P1 on the device has two executors (one thread / one wavefront per alignment, chosen by the mean alignment length); each kind
+    through the one it does not take by default: same SAM, ms:i / NM / de:f / dp_max tags included (tests/golden_env_check.py)"""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_env_check.py")
+    r = subprocess.run([sys.executable, script] + kinds, capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
