@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void map_gather_kernel(int n_box, const MapBox 
 }
 
 // compact the CIGARs of a ksw batch (each sits at the start of a qlen+tlen sized slot) into one contiguous array
-__global__ __launch_bounds__(64) void map_pack_cigar_kernel(int nb, const uint32_t *__restrict__ cig, const int64_t *__restrict__ coff,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void map_pack_cigar_kernel(int nb, const uint32_t *__restrict__ cig, const int64_t *__restrict__ coff,
                                                             const int64_t *__restrict__ poff, uint32_t *__restrict__ packed)
 {
 	const int b = blockIdx.x;
@@ -340,8 +340,9 @@ __global__ __launch_bounds__(64) void map_post_kernel(int nb, const MapBox *__re
 
 // ---- wave-parallel form of map_post_kernel: one 64-lane wavefront per alignment ---------------------------------------------------
 // One thread per alignment leaves a HiFi batch with 147 wavefronts, each lane in a 15 000-step loop of dependent loads: 22 ms per
-// 9 400 alignments, a quarter of a single batch's latency.  Here mm_fix_cigar stays with lane 0 (a few hundred operations), and the walk
-// over the bases -- mlen / blen / n_ambi and the running score of mm_update_extra -- is done by all 64 lanes.
+// 9 400 alignments, a quarter of a single batch's latency.  Here mm_fix_cigar is a kernel of its own (map_fix_cigar_kernel: a few hundred
+// operations per alignment), and the walk over the bases -- mlen / blen / n_ambi and the running score of mm_update_extra -- is done
+// by all 64 lanes of a wavefront per alignment.
 // The running score  s <- max(s + a_i, 0),  mx <- max(mx, s)  (LR/align.c:286-310; the reference updates mx only where s stays >= 0,
 // and not at gaps: the same thing, as s <= mx always holds and mx starts at 0) is a composition of maps  s -> max(s + A, B)  together
 // with the largest state seen  max(s + P, Q); for two consecutive segments x, y:
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64) void map_post_kernel(int nb, const MapBox *__re
 // which is associative, so a segment of bases can be reduced in any bracketing (every lane four bases, then an ordered tree over the
 // lanes).  It is also EXACT: the scores of bases are integers and a gap's penalty q + e * mg_log2(1 + len) -- a float times a small
 // integer -- is a multiple of 2^-30, so every sum the reference forms in its double accumulator is exactly representable (|s| < 2^20,
-// 50 bits), no addition ever rounds, and the order of additions cannot matter.  The state is kept as a 64-bit integer in units of 2^-30.
+// 50 bits), no addition ever rounds, and the order of additions cannot matter.  The state is kept as integer part + fraction in units of 2^-30.
 #define GDP_FRAC 30
 struct GdpSeg { int32_t A, B, P, Q; }; // in units of 1 (base scores are integers); B / Q = GDP_NONE: no clamp inside the segment
 #define GDP_NONE (-0x20000000)
@@ -367,6 +368,29 @@ __device__ __forceinline__ GdpSeg gdp_seg_join(const GdpSeg &x, const GdpSeg &y)
 	return r;
 }
 
+// At most 32 VGPRs (checked at build time by __graft_entry__.build through the compiler's resource remarks): the 64-lane DP kernel of the
+// next batch in flight holds 5 x 96 of a SIMD's 512 registers, so a wavefront of this size is the largest that can start BESIDE a full
+// house of DP wavefronts instead of waiting for one of them to retire (with 52 registers the kernel's 9 400 wavefronts took as long as
+// the DP kernel next to them, the batch's results arrived one DP kernel late and the pipelined step went from 88.8 to 97.6 ms).
+// first half of P1 for the wave-parallel form: mm_fix_cigar alone, one alignment per thread (a few hundred CIGAR operations each; the few
+// wavefronts this needs find room at once).  Leaves the fixed CIGAR and its length in place and the two shifts in post[b].
+__global__ __launch_bounds__(64) void map_fix_cigar_kernel(int nb, const MapBox *__restrict__ boxes, const uint8_t *__restrict__ qbuf, const uint8_t *__restrict__ tbuf,
+                                                           const int64_t *__restrict__ coff, uint32_t *__restrict__ cig, int32_t *__restrict__ n_cigar,
+                                                           const int32_t *__restrict__ score, GdPostOut *__restrict__ post)
+{
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nb) return;
+	GdPostOut P;
+	P.qshift = P.tshift = P.mlen = P.blen = P.dp_max = 0, P.n_ambi = 0;
+	const int32_t n0 = n_cigar[b];
+	if (score[b] != GD_NEG_INF_SCORE_DEV && n0 > 0 && (int64_t)n0 <= coff[b + 1] - coff[b]) {
+		uint32_t n = (uint32_t)n0;
+		gdp_fix_cigar(cig + coff[b], &n, qbuf + boxes[b].q_dst, tbuf + boxes[b].t_dst, &P.qshift, &P.tshift);
+		n_cigar[b] = (int32_t)n;
+	}
+	post[b] = P;
+}
+
 __global__ __launch_bounds__(64) void map_post_wave_kernel(int nb, const MapBox *__restrict__ boxes, const uint8_t *__restrict__ qbuf, const uint8_t *__restrict__ tbuf,
                                                            const int64_t *__restrict__ coff, uint32_t *__restrict__ cig, int32_t *__restrict__ n_cigar,
                                                            const int32_t *__restrict__ score, MapPostOpt O, GdPostOut *__restrict__ post,
@@ -376,93 +400,88 @@ __global__ __launch_bounds__(64) void map_post_wave_kernel(int nb, const MapBox 
 	const int b = blockIdx.x;
 	if (b >= nb) return;
 	const unsigned lane = threadIdx.x;
-	__shared__ int32_t s_hdr[4];
 	__shared__ int8_t s_mat[32];
 	if (lane < 25) s_mat[lane] = O.mat[lane];
 	if (lane >= 25 && lane < 32) s_mat[lane] = 0; // index past the matrix (query byte 7 against a target N): taken as 0, as gdp_update_extra does
 	GdPostOut P;
 	P.qshift = P.tshift = P.mlen = P.blen = P.dp_max = 0, P.n_ambi = 0;
-	const int32_t n0 = n_cigar[b];
-	const bool live = score[b] != GD_NEG_INF_SCORE_DEV && n0 > 0 && (int64_t)n0 <= coff[b + 1] - coff[b];
+	const int32_t n0 = __builtin_amdgcn_readfirstlane(n_cigar[b]);
+	const int32_t sc_b = __builtin_amdgcn_readfirstlane(score[b]);
+	const int64_t c0 = coff[b], c1 = coff[b + 1];
+	const bool live = sc_b != GD_NEG_INF_SCORE_DEV && n0 > 0 && (int64_t)n0 <= c1 - c0;
+	const int32_t n_out = n0;
 	if (live) {
-		uint32_t *cg = cig + coff[b];
-		const uint8_t *qseq = qbuf + boxes[b].q_dst, *tseq = tbuf + boxes[b].t_dst;
-		if (lane == 0) {
-			uint32_t n = (uint32_t)n0;
-			int32_t qs, ts;
-			gdp_fix_cigar(cg, &n, qseq, tseq, &qs, &ts);
-			s_hdr[0] = (int32_t)n, s_hdr[1] = qs, s_hdr[2] = ts;
-			__threadfence_block();
-		}
-		__syncthreads();
-		const uint32_t n = (uint32_t)s_hdr[0];
-		P.qshift = s_hdr[1], P.tshift = s_hdr[2];
+		// (everything about the alignment as a whole is wave-uniform and is kept on the scalar unit: the per-lane state is a segment, two
+		// counters and the loaded bytes)
+		uint32_t *cg = (uint32_t *)gdw_uniform_ptr((const uint8_t *)(cig + c0), 0);
+		const uint8_t *qseq = gdw_uniform_ptr(qbuf + boxes[b].q_dst, 0), *tseq = gdw_uniform_ptr(tbuf + boxes[b].t_dst, 0);
+		const uint32_t n = (uint32_t)n0; // (mm_fix_cigar has run: map_fix_cigar_kernel)
+		P.qshift = __builtin_amdgcn_readfirstlane(post[b].qshift), P.tshift = __builtin_amdgcn_readfirstlane(post[b].tshift);
+		__syncthreads(); // (s_mat)
 		qseq += P.qshift, tseq += P.tshift;
-		int64_t S = 0, MX = 0; // units of 2^-GDP_FRAC
+		// the running score S and its maximum MX as (integer part, fraction in units of 2^-GDP_FRAC, 0 <= fraction < 2^GDP_FRAC): base
+		// scores are integers, only gap penalties carry a fraction -- all scalar 32-bit arithmetic, nothing of it in vector registers
+		int32_t Si = 0, Sf = 0, MXi = 0, MXf = 0;
 		int32_t qoff = 0, toff = 0, blen = 0, mlen = 0;
 		uint32_t n_ambi_tot = 0;
 		for (uint32_t k = 0; k < n; ++k) {
-			const uint32_t c = cg[k], op = c & 0xf, len = c >> 4;
+			const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cg[k]), op = c & 0xf, len = c >> 4;
 			if (op == 0) {
-				for (uint32_t base = 0; base < len; base += 256) { // four consecutive bases per lane, then an ordered tree over the lanes
+				for (uint32_t base = 0; base < len; base += 64) { // one base per lane, then an ordered tree over the lanes
 					GdpSeg g = {0, GDP_NONE, GDP_NONE, GDP_NONE};
-					int na = 0, nd = 0;
-					const uint32_t l0 = base + 4 * lane;
-#pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						const uint32_t l = l0 + j;
-						if (l < len) {
-							const int cq = qseq[qoff + l], ct = tseq[toff + l];
-							if (ct > 3 || cq > 3) ++na;
-							else if (ct != cq) ++nd;
-							const int idx = ct * 5 + cq;
-							const int32_t a = idx < 25 ? (int32_t)s_mat[idx] : 0;
-							const GdpSeg e1 = {a, 0, a, 0}; // s -> max(s + a, 0); the state after it is max(s + a, 0) as well
-							g = gdp_seg_join(g, e1);
-						}
+					int cnt2 = 0; // n_ambi | n_diff << 16
+					const uint32_t l = base + lane;
+					if (l < len) {
+						const int cq = qseq[qoff + l], ct = tseq[toff + l];
+						if (ct > 3 || cq > 3) cnt2 = 1;
+						else if (ct != cq) cnt2 = 1 << 16;
+						const int idx = ct * 5 + cq;
+						const int32_t a = idx < 25 ? (int32_t)s_mat[idx] : 0;
+						g.A = a, g.B = 0, g.P = a, g.Q = 0; // s -> max(s + a, 0); the state after it is max(s + a, 0) as well
 					}
-#pragma unroll
+#pragma unroll 1 // (not unrolled: the kernel must stay within 32 VGPRs, see above)
 					for (int d = 1; d < 64; d <<= 1) { // lane i: segment [i, i + 2d) = its own [i, i + d) followed by lane i + d's
 						GdpSeg o;
 						o.A = __shfl_down(g.A, d), o.B = __shfl_down(g.B, d), o.P = __shfl_down(g.P, d), o.Q = __shfl_down(g.Q, d);
-						if (lane + d >= 64) o.A = 0, o.B = o.P = o.Q = GDP_NONE;
-						g = gdp_seg_join(g, o);
-						na += __shfl_down(na, d) * (lane + d < 64), nd += __shfl_down(nd, d) * (lane + d < 64);
+						const int oc = __shfl_down(cnt2, d);
+						if (lane + d < 64) g = gdp_seg_join(g, o), cnt2 += oc;
 					}
-					const int32_t A = __shfl(g.A, 0), Bc = __shfl(g.B, 0), Pm = __shfl(g.P, 0), Qm = __shfl(g.Q, 0);
-					na = __shfl(na, 0), nd = __shfl(nd, 0);
-					const int64_t one = (int64_t)1 << GDP_FRAC;
-					if (Pm != GDP_NONE) { const int64_t v = S + Pm * one; MX = MX > v ? MX : v; }
-					if (Qm != GDP_NONE) { const int64_t v = Qm * one; MX = MX > v ? MX : v; }
-					S += A * one;
-					if (Bc != GDP_NONE && S < Bc * one) S = Bc * one;
-					const uint32_t cnt = len - base < 256 ? len - base : 256;
+					const int32_t A = __builtin_amdgcn_readfirstlane(g.A), Bc = __builtin_amdgcn_readfirstlane(g.B), Pm = __builtin_amdgcn_readfirstlane(g.P),
+					              Qm = __builtin_amdgcn_readfirstlane(g.Q);
+					const int c2 = __builtin_amdgcn_readfirstlane(cnt2), na = c2 & 0xffff, nd = c2 >> 16;
+					if (Pm != GDP_NONE && (Si + Pm > MXi || (Si + Pm == MXi && Sf > MXf))) MXi = Si + Pm, MXf = Sf; // MX = max(MX, S + P)
+					if (Qm != GDP_NONE && (Qm > MXi)) MXi = Qm, MXf = 0;                                              // MX = max(MX, Q)
+					Si += A;
+					if (Bc != GDP_NONE && Si < Bc) Si = Bc, Sf = 0; // S = max(S + A, B): with 0 <= fraction < 1, S + A < B iff its integer part is
+					const uint32_t cnt = len - base < 64 ? len - base : 64;
 					blen += (int32_t)cnt - na, mlen += (int32_t)cnt - (na + nd), n_ambi_tot += (uint32_t)na;
 				}
 				toff += len, qoff += len;
 			} else if (op == 1 || op == 2) {
-				int na = 0;
+				int na = 0; // (counted with ballots: wave-uniform, no vector registers for a butterfly)
 				const uint8_t *src = op == 1 ? qseq + qoff : tseq + toff;
-				for (uint32_t l = lane; l < len; l += 64) na += src[l] > 3;
-				for (int d = 32; d > 0; d >>= 1) na += __shfl_xor(na, d);
+				for (uint32_t l0 = 0; l0 < len; l0 += 64) na += __popcll(__ballot(l0 + lane < len && src[l0 + lane] > 3));
 				blen += (int32_t)len - na, n_ambi_tot += (uint32_t)na;
 				double tot;
 				if (O.log_gap) {
 					const double pen = (double)O.e * (double)gdp_mg_log2(1.0f + (float)len);
 					tot = (double)O.q + pen;
 				} else tot = (double)(O.q + O.e);
-				S -= (int64_t)(tot * (double)((int64_t)1 << GDP_FRAC)); // exact: tot is a multiple of 2^-30 below 2^12
-				if (S < 0) S = 0;
+				// tot >= 0 is a multiple of 2^-30 below 2^12: integer part and fraction, both exact
+				const int32_t Ti = __builtin_amdgcn_readfirstlane((int32_t)tot);
+				const int32_t Tf = __builtin_amdgcn_readfirstlane((int32_t)((tot - (double)Ti) * (double)(1 << GDP_FRAC)));
+				Sf -= Tf, Si -= Ti;
+				if (Sf < 0) Sf += 1 << GDP_FRAC, Si -= 1;
+				if (Si < 0) Si = 0, Sf = 0; // (s < 0 iff its integer part is)
 				if (op == 1) qoff += len; else toff += len;
 			} else if (op == 3) toff += len;
 		}
 		P.mlen = mlen, P.blen = blen, P.n_ambi = n_ambi_tot;
-		P.dp_max = (int32_t)((double)MX / (double)((int64_t)1 << GDP_FRAC) + .499);
-		if (lane == 0) n_cigar[b] = (int32_t)n;
+		P.dp_max = (int32_t)((double)MXi + (double)MXf / (double)(1 << GDP_FRAC) + .499);
 	}
 	if (lane == 0) {
 		post[b] = P;
-		if (x_score) x_score[b] = score[b], x_ncig[b] = live ? s_hdr[0] : n_cigar[b];
+		if (x_score) x_score[b] = sc_b, x_ncig[b] = n_out;
 	}
 }
 

@@ -712,16 +712,24 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			if (xport && ctx->h_pin.p) {
 				int32_t *x_score = (int32_t *)ctx->h_pin.p, *x_ncig = x_score + nbp;
 				GdPostOut *x_post = (GdPostOut *)(x_ncig + nbp);
-				if (post_wave) hipLaunchKernelGGL(map_post_wave_kernel, dim3(nb), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
-				                                  (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, x_post, x_score, x_ncig);
+				if (post_wave) {
+					hipLaunchKernelGGL(map_fix_cigar_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+					                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, x_post);
+					hipLaunchKernelGGL(map_post_wave_kernel, dim3(nb), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+					                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, x_post, x_score, x_ncig);
+				}
 				else hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
 				                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, x_post, x_score, x_ncig);
 				h_score = x_score, h_ncig = x_ncig, h_post = x_post;
 				exported = true;
 			} else {
-				if (post_wave) hipLaunchKernelGGL(map_post_wave_kernel, dim3(nb), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
-				                                  (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p,
-				                                  (int32_t *)nullptr, (int32_t *)nullptr);
+				if (post_wave) {
+					hipLaunchKernelGGL(map_fix_cigar_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+					                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, (GdPostOut *)ctx->m_post.p);
+					hipLaunchKernelGGL(map_post_wave_kernel, dim3(nb), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
+					                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p,
+					                   (int32_t *)nullptr, (int32_t *)nullptr);
+				}
 				else hipLaunchKernelGGL(map_post_kernel, dim3((nb + 63) / 64), dim3(64), 0, sd, nb, (const MapBox *)ctx->m_boxes.p, (const uint8_t *)ctx->m_q.p,
 				                   (const uint8_t *)ctx->m_t.p, (const int64_t *)d_coff, (uint32_t *)ctx->m_cig.p, d_ncig, (const int32_t *)d_score, PO, (GdPostOut *)ctx->m_post.p,
 				                   (int32_t *)nullptr, (int32_t *)nullptr);
