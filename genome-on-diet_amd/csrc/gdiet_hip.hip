@@ -55,6 +55,8 @@ struct gdiet_ctx {
 	std::vector<int32_t> h_ids;
 	// per-read mapping path (map_pipeline.hip.h)
 	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack, m_post, m_seedids;
+	DevBuf m_srbox, m_srtab, m_srscan, m_srcand; // device-side box stage of the ShortReads variant (map_pipeline.hip.h)
+	int sr_boxes_on_device = 1;        // GDIET_SR_BOXES=host: candidate geometry of the ShortReads variant on host threads instead
 	std::vector<uint8_t> h_vo;  // host copy of the vote records' heads, kept between batches
 	DevBuf h_pin; // page-locked: scores, CIGAR lengths and P1 results of a wide-band batch, written by map_post_kernel itself
 	DevBuf h_boxes, h_cand, h_tasks, h_seedout, h_res, h_cig, h_post; // HOST buffers kept between batches (gd_host_grow): the per-batch tables of a
@@ -225,6 +227,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (ib) ctx->index_on_device = strcmp(ib, "host") != 0;
 		const char *po = getenv("GDIET_POST");
 		if (po) ctx->post_on_device = strcmp(po, "host") != 0;
+		const char *sb = getenv("GDIET_SR_BOXES");
+		if (sb) ctx->sr_boxes_on_device = strcmp(sb, "host") != 0;
 		const char *fb = getenv("GDIET_FUSE_BT");
 		if (fb) ctx->fuse_bt = atoi(fb) != 0;
 		const char *ds = getenv("GDIET_DP_SPLIT");

@@ -78,14 +78,8 @@ struct GdCand { // vt_t of LR/map.c:1033-1045 plus the DP box
 	int32_t exact_score = GD_NEG_INF_SCORE; // != NEG_INF: try the exact-match pre-filter (LR/map.c:1748)
 };
 
-// a candidate between the box stage and the post-processing, without its (still empty) record: trivially copyable, so that the
-// candidates of a whole batch can live in one reused flat buffer
-struct GdCandBox {
-	GdVt v;
-	int next, concat, valid;
-	uint32_t target_id, target_start, target_end, query_start, query_end, qlen, tlen, qseq_off;
-	int32_t exact_score;
-};
+// (GdCandBox -- a candidate between the box stage and the post-processing, trivially copyable -- lives in map_stages.h: the ShortReads
+// box stage also runs on the device)
 static inline GdCandBox gd_cand_box(const GdCand &c)
 {
 	GdCandBox b;
@@ -531,66 +525,7 @@ static inline void gd_lr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 // DP box of one short-read candidate (SR/map.c:780-930); false: the candidate is dropped
 static inline bool gd_sr_box_one(const GdVt &v, const GdMapOpt &O, const GdRefView &R, uint32_t qlen_sum, GdCandBox &b)
 {
-	const int str = (int)v.str;
-	const uint32_t target_id = v.chrom_id;
-	uint32_t start_offset, end_offset;
-	int32_t target_loc = v.first_target_loc;
-	if (str) target_loc -= (O.k - 1);
-	int32_t target_start = target_loc, target_end = target_loc;
-	const int32_t tlen = target_id < R.n_seq ? (int32_t)R.seq[target_id].len : 0;
-	if (qlen_sum > 300) {
-		if (v.first_query_loc == v.last_query_loc) return false;
-		start_offset = v.first_query_loc - (uint32_t)(O.k - 1);
-		end_offset = v.last_query_loc;
-		if (str) {
-			target_end = (int32_t)((uint32_t)target_end - start_offset);
-			target_start = (int32_t)((uint32_t)target_start - end_offset);
-			if (target_start < 0) {
-				end_offset += (uint32_t)target_start;
-				target_start = 0;
-			}
-		} else {
-			target_start = (int32_t)((uint32_t)target_start + start_offset);
-			target_end = (int32_t)((uint32_t)target_end + end_offset);
-			if (target_end + 1 > tlen) {
-				end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
-				target_end = tlen - 1;
-			}
-		}
-	} else {
-		if (str) {
-			if (target_end > tlen - 1) {
-				start_offset = (uint32_t)(target_end - (tlen - 1));
-				target_end = tlen - 1;
-			} else start_offset = 0;
-			if ((uint32_t)target_end < qlen_sum - start_offset - 1) { // int32 against unsigned: compared as unsigned (:816)
-				end_offset = start_offset + (uint32_t)target_end;
-				target_start = 0;
-			} else {
-				end_offset = qlen_sum - 1;
-				target_start = (int32_t)((uint32_t)target_end - (end_offset - start_offset));
-			}
-		} else {
-			if (target_start < 0) {
-				start_offset = (uint32_t)(-target_start);
-				target_start = 0;
-			} else start_offset = 0;
-			if ((uint32_t)(tlen - target_start) < qlen_sum - start_offset) { // (:831) unsigned compare as well
-				end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
-				target_end = tlen - 1;
-			} else {
-				end_offset = qlen_sum - 1;
-				target_end = (int32_t)((uint32_t)target_start + (end_offset - start_offset));
-			}
-		}
-	}
-	const uint32_t len = end_offset - start_offset + 1;
-	b.v = v, b.next = -1, b.concat = 0, b.valid = 1;
-	b.target_id = target_id, b.target_start = (uint32_t)target_start, b.target_end = (uint32_t)target_end;
-	b.query_start = start_offset, b.query_end = end_offset, b.qlen = len, b.tlen = len;
-	b.qseq_off = str ? qlen_sum - 1 - end_offset : start_offset; // qs = &qs_rev[qlen_sum-1-end_offset] / &qs_for[start_offset]
-	b.exact_score = qlen_sum < 300 ? (int32_t)(qlen_sum * (uint32_t)O.a) : GD_NEG_INF_SCORE; // :873-908
-	return true;
+	return gd_sr_box_core(v, O.k, O.a, qlen_sum, v.chrom_id < R.n_seq ? (int32_t)R.seq[v.chrom_id].len : 0, b);
 }
 
 static inline void gd_sr_boxes(std::vector<GdCand> &C, const GdMapOpt &O, const GdRefView &R, uint32_t qlen_sum)

@@ -304,6 +304,75 @@ __global__ __launch_bounds__(64) void map_gather_kernel(int n_box, const MapBox 
 	}
 }
 
+// ---- G2 on the device (ShortReads variant): the voted diagonals of every read become DP boxes, MapBox records and
+// the offset tables of the DP batch without the candidates visiting the host first.  Per 262 144 reads the host stages this replaces
+// took 12 ms of a 16-thread pool (boxes 5.7, offsets 2.0, window table 4.8) -- as long as the GPU needs for the whole batch.
+//   map_sr_box_kernel : per read, gd_sr_box_core (SR/map.c:779-839) on each of its candidates -> its boxes in a slot of its own, their
+//                       number and the sum of their lengths (a box is len x len); a read with a degenerate box gives none and is counted
+//   (two exclusive scans: first box index and first window offset of every read)
+//   map_sr_fill_kernel: per read, its boxes into the dense tables: MapBox (what map_gather_kernel reads), GdCandBox (what the host's
+//                       record stage reads), window / CIGAR offsets, band width and exact-match score per box (what the DP planner reads)
+struct MapSrTotals { int32_t n_failed, last_failed; };
+__global__ __launch_bounds__(64) void map_sr_box_kernel(int n_reads, const int64_t *__restrict__ roff, const MapVoteOut *__restrict__ vo, const uint32_t *__restrict__ seq_len,
+                                                        uint32_t n_seq, int k, int a, int slots, int fault_read, GdCandBox *__restrict__ sbox, int32_t *__restrict__ cnt,
+                                                        int64_t *__restrict__ sumlen, MapSrTotals *__restrict__ tot)
+{
+	const int rid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rid >= n_reads) return;
+	const uint32_t rl = (uint32_t)(roff[rid + 1] - roff[rid]);
+	const unsigned nc = vo[rid].n_cand;
+	GdCandBox *out = sbox + (size_t)rid * slots;
+	int m = 0;
+	int64_t sl = 0;
+	bool bad = rid == fault_read && nc > 0;
+	for (unsigned j = 0; j < nc && m < slots; ++j) {
+		const GdVt v = vo[rid].cand[j];
+		GdCandBox b;
+		if (!gd_sr_box_core(v, k, a, rl, v.chrom_id < n_seq ? (int32_t)seq_len[v.chrom_id] : 0, b)) continue;
+		bad |= b.qlen == 0 || b.tlen == 0 || b.qlen > rl || b.qseq_off + b.qlen > rl || b.tlen > 8u * rl + 100000u;
+		out[m++] = b, sl += b.qlen;
+	}
+	if (bad) { m = 0, sl = 0; atomicAdd(&tot->n_failed, 1), atomicMax(&tot->last_failed, rid); }
+	cnt[rid] = m, sumlen[rid] = sl;
+}
+
+struct MapSrFillOut { // dense per-box tables, all on the device (the host gets copies of cand, qoff, coff, bw, ex)
+	MapBox *boxes;
+	GdCandBox *cand;
+	int64_t *qoff, *coff; // nb + 1 entries; the window of a box is len bases of the read and len of the reference: toff == qoff
+	int32_t *bw, *ex;
+};
+__global__ __launch_bounds__(64) void map_sr_fill_kernel(int n_reads, const int64_t *__restrict__ roff, const int32_t *__restrict__ cnt, const int32_t *__restrict__ box_first,
+                                                         const int64_t *__restrict__ len_first, const GdCandBox *__restrict__ sbox, int slots,
+                                                         const uint32_t *__restrict__ seq_len, const uint64_t *__restrict__ seq_off, uint32_t n_seq, GdSrVoteOpt sr, MapSrFillOut O)
+{
+	const int rid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (rid > n_reads) return;
+	if (rid == n_reads) { // the closing entries of the offset tables
+		O.qoff[box_first[n_reads]] = len_first[n_reads], O.coff[box_first[n_reads]] = 2 * len_first[n_reads];
+		return;
+	}
+	const uint32_t rl = (uint32_t)(roff[rid + 1] - roff[rid]);
+	const int m = cnt[rid];
+	int64_t off = len_first[rid];
+	const int32_t bw = (int32_t)gd_sr_bw((int)rl, sr); // SR/map.c:624-631,925
+	for (int j = 0; j < m; ++j) {
+		const GdCandBox c = sbox[(size_t)rid * slots + j];
+		const int b = box_first[rid] + j;
+		MapBox M;
+		M.read_off = roff[rid], M.read_len = rl, M.qseq_off = c.qseq_off, M.qlen = c.qlen, M.tlen = c.tlen, M.rev = c.v.str;
+		uint32_t avail = 0;
+		uint64_t src = 0;
+		if (c.target_id < n_seq && c.target_start < seq_len[c.target_id]) { // (a window hanging off its contig: the missing part is zero-filled)
+			const uint32_t left = seq_len[c.target_id] - c.target_start;
+			avail = c.tlen < left ? c.tlen : left, src = seq_off[c.target_id] + c.target_start;
+		}
+		M.t_avail = avail, M.t_src = src, M.q_dst = off, M.t_dst = off;
+		O.boxes[b] = M, O.cand[b] = c, O.qoff[b] = off, O.coff[b] = 2 * off, O.bw[b] = bw, O.ex[b] = c.exact_score;
+		off += c.qlen;
+	}
+}
+
 // compact the CIGARs of a ksw batch (each sits at the start of a qlen+tlen sized slot) into one contiguous array
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void map_pack_cigar_kernel(int nb, const uint32_t *__restrict__ cig, const int64_t *__restrict__ coff,
                                                             const int64_t *__restrict__ poff, uint32_t *__restrict__ packed)

@@ -20,6 +20,10 @@ struct gdiet_index {
 	bool host_tables = true;
 	uint32_t *d_cnt_sorted = nullptr; // occurrence counts of the keys, ascending (mm_idx_cal_max_occ)
 	uint64_t n_pos = 0;
+	// contig table on the device (lengths, offsets into S), made on first use by the device-side box stage of the ShortReads variant
+	uint32_t *d_seq_len = nullptr;
+	uint64_t *d_seq_off = nullptr;
+	std::mutex seq_mu;
 };
 
 struct gdiet_read_batch {
@@ -170,7 +174,7 @@ extern "C" void gdiet_hip_index_destroy(gdiet_ctx *ctx, gdiet_index *ix)
 {
 	if (!ix) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
-	void *p[] = {ix->d_tkey, ix->d_tval, ix->d_pos, ix->d_S, ix->d_cnt_sorted};
+	void *p[] = {ix->d_tkey, ix->d_tval, ix->d_pos, ix->d_S, ix->d_cnt_sorted, ix->d_seq_len, ix->d_seq_off};
 	for (void *q : p) if (q) (void)hipFree(q);
 	delete ix;
 }
@@ -527,6 +531,118 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		                   (const GdSeed *)ctx->m_seed.p, (const MapSeedOut *)ctx->m_seedout.p, (const int64_t *)ctx->m_hitoff.p, (GdLoc *)ctx->m_hits.p,
 		                   (MapVoteOut *)ctx->m_voteout.p, spread);
 	GD_HIP(hipGetLastError());
+	// ---- G1b / G2 ---------------------------------------------------------------------------------------------------------------
+	// ShortReads: the box stage on the device (map_sr_box_kernel / map_sr_fill_kernel): the candidates never visit the host; what comes
+	// back are the dense per-box tables the DP planner and the record stage read.  GDIET_SR_BOXES=host keeps the host stages.
+	const bool sr_dev = is_sr && ctx->sr_boxes_on_device && (int64_t)n * std::min<int64_t>(O.af_max_loc, GDM_MAX_VT) < ((int64_t)1 << 28);
+	const GdRefView R = ix->h.ref();
+	std::vector<int> cfirst(n + 1, 0), ccount(n, 0), box_first(n + 1, 0);
+	GdCandBox *cflat = nullptr;
+	int nb = 0;
+	MapBox *boxes = nullptr;
+	std::vector<int64_t> qoff, toff, coff;
+	std::vector<int32_t> bw, ex;
+	size_t nbp = 64;
+	int64_t *d_coff = nullptr;
+	int32_t *d_ex = nullptr, *d_score = nullptr, *d_ncig = nullptr;
+	auto aux_layout = [&]() -> int { // d_coff | d_ex | d_score | d_ncig in one buffer, the last three 256-byte aligned as their host copies
+		nbp = ((size_t)std::max(nb, 1) + 63) & ~(size_t)63;
+		int rc2;
+		if ((rc2 = gd_grow(ctx, ctx->m_aux, sizeof(int64_t) * (nb + 1) + sizeof(int32_t) * 3 * nbp + 1024))) return rc2;
+		d_coff = (int64_t *)ctx->m_aux.p;
+		d_ex = (int32_t *)(((uintptr_t)(d_coff + nb + 1) + 255) & ~(uintptr_t)255), d_score = d_ex + nbp, d_ncig = d_score + nbp;
+		return GDIET_OK;
+	};
+	if (sr_dev) {
+		const int slots = (int)std::min<int64_t>(O.af_max_loc, GDM_MAX_VT);
+		{ // the contig table of the index on the device (once)
+			gdiet_index *ixm = const_cast<gdiet_index *>(ix);
+			std::lock_guard<std::mutex> lk(ixm->seq_mu);
+			if (!ixm->d_seq_len) {
+				std::vector<uint32_t> sl(R.n_seq);
+				std::vector<uint64_t> so(R.n_seq);
+				for (uint32_t q = 0; q < R.n_seq; ++q) sl[q] = R.seq[q].len, so[q] = R.seq[q].offset;
+				uint32_t *dl = nullptr;
+				uint64_t *d_o = nullptr;
+				GD_HIP(hipMalloc(&dl, sizeof(uint32_t) * std::max<size_t>(R.n_seq, 1)));
+				GD_HIP(hipMalloc(&d_o, sizeof(uint64_t) * std::max<size_t>(R.n_seq, 1)));
+				GD_HIP(hipMemcpy(dl, sl.data(), sizeof(uint32_t) * R.n_seq, hipMemcpyHostToDevice));
+				GD_HIP(hipMemcpy(d_o, so.data(), sizeof(uint64_t) * R.n_seq, hipMemcpyHostToDevice));
+				ixm->d_seq_off = d_o, ixm->d_seq_len = dl;
+			}
+		}
+		// per-read tables: cnt[n] | box_first[n + 1] (int32), sumlen[n] | len_first[n + 1] (int64), totals
+		const size_t tab_bytes = sizeof(int64_t) * (2 * (size_t)n + 2) + sizeof(int32_t) * (2 * (size_t)n + 2) + sizeof(MapSrTotals) + 64;
+		if ((rc = gd_grow(ctx, ctx->m_srtab, tab_bytes))) return rc;
+		if ((rc = gd_grow(ctx, ctx->m_srbox, sizeof(GdCandBox) * (size_t)n * slots))) return rc;
+		int64_t *d_sumlen = (int64_t *)ctx->m_srtab.p, *d_lenfirst = d_sumlen + n;
+		int32_t *d_cnt = (int32_t *)(d_lenfirst + n + 1), *d_boxfirst = d_cnt + n;
+		MapSrTotals *d_tot = (MapSrTotals *)(d_boxfirst + n + 1);
+		static const char *fault_env = getenv("GDIET_FAULT_BOX");
+		const MapSrTotals zero = {0, -1};
+		GD_HIP(hipMemcpyAsync(d_tot, &zero, sizeof zero, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(map_sr_box_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_roff, (const MapVoteOut *)ctx->m_voteout.p, (const uint32_t *)ix->d_seq_len, R.n_seq,
+		                   O.k, O.a, slots, fault_env ? atoi(fault_env) : -1, (GdCandBox *)ctx->m_srbox.p, d_cnt, d_sumlen, d_tot);
+		// exclusive scans over n + 1 entries (the last input is never read as a value: the scans' last outputs are the totals)
+		size_t b1 = 0, b2 = 0;
+		GD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b1, d_cnt, d_boxfirst, n + 1, s));
+		GD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, d_sumlen, d_lenfirst, n + 1, s));
+		if ((rc = gd_grow(ctx, ctx->m_srscan, std::max(b1, b2) + 64))) return rc;
+		size_t bb = ctx->m_srscan.cap;
+		GD_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->m_srscan.p, bb, d_cnt, d_boxfirst, n + 1, s));
+		bb = ctx->m_srscan.cap;
+		GD_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->m_srscan.p, bb, d_sumlen, d_lenfirst, n + 1, s));
+		// the two totals and the failure count: 24 bytes, the only thing the host waits for before it can size the batch's buffers
+		struct { int32_t nb; int32_t pad; int64_t bases; MapSrTotals t; } h_tot;
+		GD_HIP(hipMemcpyAsync(&h_tot.nb, d_boxfirst + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+		GD_HIP(hipMemcpyAsync(&h_tot.bases, d_lenfirst + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+		GD_HIP(hipMemcpyAsync(&h_tot.t, d_tot, sizeof(MapSrTotals), hipMemcpyDeviceToHost, s));
+		GD_HIP(gd_stream_wait(ctx, s));
+		ctx->stage_s[1] += gd_now() - t0, t0 = gd_now();
+		mark("vote");
+		nb = h_tot.nb;
+		ctx->failed_last = h_tot.t.n_failed, ctx->failed_total += h_tot.t.n_failed;
+		if (h_tot.t.n_failed) {
+			char msg[160];
+			snprintf(msg, sizeof msg, "%lld read(s) of the batch left unmapped: degenerate DP box (candidate window outside the read / contig), last: read %d of the call",
+			         (long long)h_tot.t.n_failed, h_tot.t.last_failed);
+			ctx->warn = msg;
+		}
+		if ((rc = aux_layout())) return rc;
+		if (nb > 0) {
+			if ((rc = gd_grow(ctx, ctx->m_boxes, sizeof(MapBox) * (size_t)nb))) return rc;
+			if ((rc = gd_grow(ctx, ctx->m_srcand, sizeof(GdCandBox) * (size_t)nb + sizeof(int64_t) * ((size_t)nb + 1) + sizeof(int32_t) * (size_t)nb + 256))) return rc;
+			GdCandBox *d_cand = (GdCandBox *)ctx->m_srcand.p;
+			int64_t *d_qoff = (int64_t *)(((uintptr_t)(d_cand + nb) + 63) & ~(uintptr_t)63);
+			int32_t *d_bw = (int32_t *)(d_qoff + nb + 1);
+			MapSrFillOut FO = {(MapBox *)ctx->m_boxes.p, d_cand, d_qoff, d_coff, d_bw, d_ex};
+			hipLaunchKernelGGL(map_sr_fill_kernel, dim3((n + 1 + 63) / 64), dim3(64), 0, s, n, d_roff, (const int32_t *)d_cnt, (const int32_t *)d_boxfirst, (const int64_t *)d_lenfirst,
+			                   (const GdCandBox *)ctx->m_srbox.p, slots, (const uint32_t *)ix->d_seq_len, (const uint64_t *)ix->d_seq_off, R.n_seq, D.sr, FO);
+			// host copies of what the planner and the record stage read
+			if ((rc = gd_host_grow(ctx, ctx->h_cand, sizeof(GdCandBox) * (size_t)nb))) return rc;
+			cflat = (GdCandBox *)ctx->h_cand.p;
+			qoff.resize(nb + 1), coff.resize(nb + 1), bw.resize(nb), ex.resize(nb);
+			GD_HIP(hipMemcpyAsync(cflat, d_cand, sizeof(GdCandBox) * (size_t)nb, hipMemcpyDeviceToHost, s));
+			GD_HIP(hipMemcpyAsync(qoff.data(), d_qoff, sizeof(int64_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost, s));
+			GD_HIP(hipMemcpyAsync(coff.data(), d_coff, sizeof(int64_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost, s));
+			GD_HIP(hipMemcpyAsync(bw.data(), d_bw, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, s));
+			GD_HIP(hipMemcpyAsync(ex.data(), d_ex, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, s));
+		} else qoff.assign(1, 0), coff.assign(1, 0);
+		GD_HIP(hipMemcpyAsync(ccount.data(), d_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+		// the windows can be gathered while the tables travel (same stream: the gather kernel is queued behind the fill kernel)
+		if (nb > 0) {
+			if ((rc = gd_grow(ctx, ctx->m_q, (size_t)h_tot.bases + 64))) return rc;
+			if ((rc = gd_grow(ctx, ctx->m_t, (size_t)h_tot.bases + 64))) return rc;
+			if ((rc = gd_grow(ctx, ctx->m_cig, sizeof(uint32_t) * (2 * (size_t)h_tot.bases + 1)))) return rc;
+			hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(64), 0, s, nb, (const MapBox *)ctx->m_boxes.p, d_reads, (const uint32_t *)ix->d_S,
+			                   (uint8_t *)ctx->m_q.p, (uint8_t *)ctx->m_t.p);
+		}
+		GD_HIP(gd_stream_wait(ctx, s));
+		for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + ccount[i];
+		cfirst = box_first;
+		if (box_first[n] != nb) { ctx->err = "box tables of the device and the host disagree"; return GDIET_E_HIP; }
+		toff = qoff;
+	} else {
 	// only the head of every record can be in use: n_cand + at most AF_max_loc (ShortReads) / vt_nb_loc + 2 (LongReads) candidates;
 	// the host copy is packed to that size (a full-size array would be 680 B per read: 178 MB to allocate and clear per 262 k short reads)
 	const size_t vo_head = offsetof(MapVoteOut, cand) + sizeof(GdVt) * std::min<size_t>(is_sr ? (size_t)O.af_max_loc : (size_t)O.vt_nb_loc + 2, GDM_MAX_VT);
@@ -537,14 +653,12 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	ctx->stage_s[1] += gd_now() - t0, t0 = gd_now();
 	mark("vote");
 	// ---- G1b: linking + DP boxes (host threads) ------------------------------------------------------------------------
-	const GdRefView R = ix->h.ref();
 	// candidates of all reads in one flat array (capacity: what the vote kernel reported; the box stage may drop some).  Per-read
 	// vectors would be allocated by the workers and released by this thread -- a quarter of a million cross-thread frees per
 	// short-read batch, each contending for another thread's malloc arena.
-	std::vector<int> cfirst(n + 1, 0), ccount(n, 0);
 	for (int i = 0; i < n; ++i) cfirst[i + 1] = cfirst[i] + (int)reinterpret_cast<const MapVoteOut *>(vo_raw + vo_head * (size_t)i)->n_cand;
 	if ((rc = gd_host_grow(ctx, ctx->h_cand, sizeof(GdCandBox) * (size_t)cfirst[n]))) return rc;
-	GdCandBox *cflat = (GdCandBox *)ctx->h_cand.p; // entries [cfirst[i], cfirst[i] + ccount[i]) are written below, nothing else is read
+	cflat = (GdCandBox *)ctx->h_cand.p; // entries [cfirst[i], cfirst[i] + ccount[i]) are written below, nothing else is read
 	mark("g:prefix");
 	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
 		const MapVoteOut &vo_i = *reinterpret_cast<const MapVoteOut *>(vo_raw + vo_head * (size_t)i); // head of the record only
@@ -589,14 +703,13 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			ctx->warn = msg;
 		}
 	}
-	std::vector<int> box_first(n + 1, 0);
 	for (int i = 0; i < n; ++i) box_first[i + 1] = box_first[i] + ccount[i];
 	mark("g:boxes");
-	const int nb = box_first[n];
+	nb = box_first[n];
 	if ((rc = gd_host_grow(ctx, ctx->h_boxes, sizeof(MapBox) * (size_t)std::max(nb, 1)))) return rc;
-	MapBox *boxes = (MapBox *)ctx->h_boxes.p;
-	std::vector<int64_t> qoff(nb + 1, 0), toff(nb + 1, 0), coff(nb + 1, 0);
-	std::vector<int32_t> bw(nb), ex(nb);
+	boxes = (MapBox *)ctx->h_boxes.p;
+	qoff.assign(nb + 1, 0), toff.assign(nb + 1, 0), coff.assign(nb + 1, 0);
+	bw.resize(nb), ex.resize(nb);
 	// window offsets: a running sum over the boxes in batch order; the boxes themselves are filled by the host threads
 	for (int i = 0; i < n; ++i)
 		for (int j = 0; j < ccount[i]; ++j) {
@@ -626,6 +739,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 			bw[b] = is_sr ? (int32_t)gd_sr_bw((int)rl, D.sr) : (int32_t)O.bw, ex[b] = c.exact_score; // SR/map.c:624-631,925 ; LR/map.c:1800
 		}
 	});
+	}
 	ctx->stage_s[2] += gd_now() - t0, t0 = gd_now();
 	mark("g:fill");
 	// scores | CIGAR lengths come back in ONE copy with both ends 256-byte aligned.  (As two copies the second, starting at an address
@@ -634,7 +748,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// 37 KB copy then finished only in the tail of the other batch's DP kernel, 45-60 ms later (kernel trace, round 2): invisible in
 	// the throughput with three batches in flight, but it is the batch's latency.  Pinned host buffers were tried as well and cost 8 %
 	// of the step: the host stages write these tables.)
-	const size_t nbp = ((size_t)std::max(nb, 1) + 63) & ~(size_t)63;
+	nbp = ((size_t)std::max(nb, 1) + 63) & ~(size_t)63;
 	if ((rc = gd_host_grow(ctx, ctx->h_res, sizeof(int32_t) * 2 * nbp))) return rc;
 	int32_t *h_score = (int32_t *)ctx->h_res.p, *h_ncig = h_score + nbp;
 	const bool post_dev = ctx->post_on_device != 0;
@@ -648,18 +762,18 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	// smaller batches measured slower): the DP stages take turns
 	std::unique_lock<std::mutex> dp_lock;
 	if (nb > 0) {
-		if ((rc = gd_grow(ctx, ctx->m_boxes, sizeof(MapBox) * nb))) return rc;
-		if ((rc = gd_grow(ctx, ctx->m_q, (size_t)qoff[nb] + 64))) return rc;
-		if ((rc = gd_grow(ctx, ctx->m_t, (size_t)toff[nb] + 64))) return rc;
-		if ((rc = gd_grow(ctx, ctx->m_aux, sizeof(int64_t) * (nb + 1) + sizeof(int32_t) * 3 * nbp + 1024))) return rc;
-		if ((rc = gd_grow(ctx, ctx->m_cig, sizeof(uint32_t) * ((size_t)coff[nb] + 1)))) return rc;
-		int64_t *d_coff = (int64_t *)ctx->m_aux.p;
-		int32_t *d_ex = (int32_t *)(((uintptr_t)(d_coff + nb + 1) + 255) & ~(uintptr_t)255), *d_score = d_ex + nbp, *d_ncig = d_score + nbp; // 256-byte aligned, as the host side
-		GD_HIP(hipMemcpyAsync(ctx->m_boxes.p, boxes, sizeof(MapBox) * nb, hipMemcpyHostToDevice, s));
-		GD_HIP(hipMemcpyAsync(d_coff, coff.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, s));
-		GD_HIP(hipMemcpyAsync(d_ex, ex.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
-		hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(64), 0, s, nb, (const MapBox *)ctx->m_boxes.p, d_reads, (const uint32_t *)ix->d_S,
-		                   (uint8_t *)ctx->m_q.p, (uint8_t *)ctx->m_t.p);
+		if (!sr_dev) { // (device-side box stage: the tables are on the device already and the windows gathered)
+			if ((rc = gd_grow(ctx, ctx->m_boxes, sizeof(MapBox) * nb))) return rc;
+			if ((rc = gd_grow(ctx, ctx->m_q, (size_t)qoff[nb] + 64))) return rc;
+			if ((rc = gd_grow(ctx, ctx->m_t, (size_t)toff[nb] + 64))) return rc;
+			if ((rc = aux_layout())) return rc;
+			if ((rc = gd_grow(ctx, ctx->m_cig, sizeof(uint32_t) * ((size_t)coff[nb] + 1)))) return rc;
+			GD_HIP(hipMemcpyAsync(ctx->m_boxes.p, boxes, sizeof(MapBox) * nb, hipMemcpyHostToDevice, s));
+			GD_HIP(hipMemcpyAsync(d_coff, coff.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, s));
+			GD_HIP(hipMemcpyAsync(d_ex, ex.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, s));
+			hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(64), 0, s, nb, (const MapBox *)ctx->m_boxes.p, d_reads, (const uint32_t *)ix->d_S,
+			                   (uint8_t *)ctx->m_q.p, (uint8_t *)ctx->m_t.p);
+		}
 		gdiet_ksw_score_t ks;
 		ks.match = (int8_t)O.a, ks.mismatch = (int8_t)(O.b < 0 ? O.b : -O.b), ks.sc_ambi = 0, ks.q = (int8_t)O.q, ks.e = (int8_t)O.e, ks.q2 = (int8_t)O.q2, ks.e2 = (int8_t)O.e2;
 		ks.reserved = 0, ks.flag = GDIET_EZ_APPROX_MAX;

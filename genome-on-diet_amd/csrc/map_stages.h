@@ -747,3 +747,80 @@ GDM_HD unsigned gd_sr_candidates(LocSrc a_for, unsigned n_for, LocSrc a_rev, uns
 	}
 	return nb;
 }
+
+// ---- G2: candidate geometry of the ShortReads variant, SR/map.c:779-839, as plain arithmetic for both sides (the host stages call
+// it through gd_sr_box_one, map_host.h; on the device map_sr_box_kernel does) --------------------------------------------------------
+#ifndef GD_NEG_INF_SCORE
+#define GD_NEG_INF_SCORE (-0x40000000)
+#endif
+// a candidate between the box stage and the post-processing, without its (still empty) record: trivially copyable, so that the
+// candidates of a whole batch can live in one reused flat buffer
+struct GdCandBox {
+	GdVt v;
+	int next, concat, valid;
+	uint32_t target_id, target_start, target_end, query_start, query_end, qlen, tlen, qseq_off;
+	int32_t exact_score;
+};
+// tlen: length of the contig v.chrom_id (0 when the id is out of range); false: the reference skips the candidate (:796-801)
+GDM_HD bool gd_sr_box_core(const GdVt &v, int k_, int a_, uint32_t qlen_sum, int32_t tlen, GdCandBox &b)
+{
+	const int str = (int)v.str;
+	const uint32_t target_id = v.chrom_id;
+	uint32_t start_offset, end_offset;
+	int32_t target_loc = v.first_target_loc;
+	if (str) target_loc -= (k_ - 1);
+	int32_t target_start = target_loc, target_end = target_loc;
+	if (qlen_sum > 300) {
+		if (v.first_query_loc == v.last_query_loc) return false;
+		start_offset = v.first_query_loc - (uint32_t)(k_ - 1);
+		end_offset = v.last_query_loc;
+		if (str) {
+			target_end = (int32_t)((uint32_t)target_end - start_offset);
+			target_start = (int32_t)((uint32_t)target_start - end_offset);
+			if (target_start < 0) {
+				end_offset += (uint32_t)target_start;
+				target_start = 0;
+			}
+		} else {
+			target_start = (int32_t)((uint32_t)target_start + start_offset);
+			target_end = (int32_t)((uint32_t)target_end + end_offset);
+			if (target_end + 1 > tlen) {
+				end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
+				target_end = tlen - 1;
+			}
+		}
+	} else {
+		if (str) {
+			if (target_end > tlen - 1) {
+				start_offset = (uint32_t)(target_end - (tlen - 1));
+				target_end = tlen - 1;
+			} else start_offset = 0;
+			if ((uint32_t)target_end < qlen_sum - start_offset - 1) { // int32 against unsigned: compared as unsigned (:816)
+				end_offset = start_offset + (uint32_t)target_end;
+				target_start = 0;
+			} else {
+				end_offset = qlen_sum - 1;
+				target_start = (int32_t)((uint32_t)target_end - (end_offset - start_offset));
+			}
+		} else {
+			if (target_start < 0) {
+				start_offset = (uint32_t)(-target_start);
+				target_start = 0;
+			} else start_offset = 0;
+			if ((uint32_t)(tlen - target_start) < qlen_sum - start_offset) { // (:831) unsigned compare as well
+				end_offset = (uint32_t)(tlen - 1 - target_start) + start_offset;
+				target_end = tlen - 1;
+			} else {
+				end_offset = qlen_sum - 1;
+				target_end = (int32_t)((uint32_t)target_start + (end_offset - start_offset));
+			}
+		}
+	}
+	const uint32_t len = end_offset - start_offset + 1;
+	b.v = v, b.next = -1, b.concat = 0, b.valid = 1;
+	b.target_id = target_id, b.target_start = (uint32_t)target_start, b.target_end = (uint32_t)target_end;
+	b.query_start = start_offset, b.query_end = end_offset, b.qlen = len, b.tlen = len;
+	b.qseq_off = str ? qlen_sum - 1 - end_offset : start_offset; // qs = &qs_rev[qlen_sum-1-end_offset] / &qs_for[start_offset]
+	b.exact_score = qlen_sum < 300 ? (int32_t)(qlen_sum * (uint32_t)a_) : GD_NEG_INF_SCORE; // :873-908
+	return true;
+}
