@@ -369,8 +369,14 @@ struct GdBatchView {
 	const int64_t *d_roff; // device copy of roff (already offset to the slice)
 };
 
+// B4 (gdiet_hip_seed_batch): what the seeding stage leaves, copied out right behind the seed kernel instead of going on
+struct GdSeedExport {
+	std::vector<MapSeedOut> out;   // per read: shift, tmp_extracted_len, n_mv, n_seeds, n_a
+	std::vector<GdSeed> seeds;     // the kept seeds of all reads, back to back
+};
+
 // the whole per-read path for one slice, on ctx's own stream and buffers (ctx is a lane: the parent context or one of its children)
-static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O, const GdBatchView &B, int32_t *n_regs, gdiet_reg_t **regs)
+static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O, const GdBatchView &B, int32_t *n_regs, gdiet_reg_t **regs, GdSeedExport *sx = nullptr)
 {
 	// GDIET_TRACE_STAGES=1: wall time of the host-side sub-steps of this call to stderr (development aid)
 	static const bool trace = getenv("GDIET_TRACE_STAGES") != nullptr;
@@ -389,7 +395,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	const int n = B.n;
 	for (int i = 0; i < 6; ++i) ctx->stage_s[i] = 0;
 	if (n == 0) return GDIET_OK;
-	for (int i = 0; i < n; ++i) n_regs[i] = 0, regs[i] = nullptr; // whatever happens below, gdiet_hip_free_regs on these arrays is safe
+	if (!sx) for (int i = 0; i < n; ++i) n_regs[i] = 0, regs[i] = nullptr; // whatever happens below, gdiet_hip_free_regs on these arrays is safe
 	hipStream_t s = ctx->stream;
 	int rc;
 	double t0 = gd_now();
@@ -504,6 +510,20 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	}
 	ctx->stage_s[0] += gd_now() - t0, t0 = gd_now();
 	mark("seed");
+	if (sx) { // B4: the seeds themselves are the result
+		sx->out.assign(so, so + n);
+		int64_t tot_seeds = 0;
+		for (int i = 0; i < n; ++i) tot_seeds += so[i].n_seeds > 0 ? so[i].n_seeds : 0;
+		sx->seeds.resize((size_t)tot_seeds);
+		int64_t at = 0;
+		for (int i = 0; i < n; ++i)
+			if (so[i].n_seeds > 0) {
+				GD_HIP(hipMemcpyAsync(sx->seeds.data() + at, (const GdSeed *)ctx->m_seed.p + sc[i].seed_off, sizeof(GdSeed) * (size_t)so[i].n_seeds, hipMemcpyDeviceToHost, s));
+				at += so[i].n_seeds;
+			}
+		GD_HIP(gd_stream_wait(ctx, s));
+		return GDIET_OK;
+	}
 	std::vector<int64_t> hoff(n + 1, 0);
 	for (int i = 0; i < n; ++i) {
 		hoff[i + 1] = hoff[i] + (so[i].n_seeds > 0 ? so[i].n_a : 0);
@@ -1103,6 +1123,64 @@ extern "C" int gdiet_hip_map_batch(gdiet_ctx *ctx, const gdiet_index *ix, const 
 	rc = gdiet_hip_map_uploaded(ctx, ix, opt, b, n_regs, regs);
 	gdiet_hip_batch_destroy(ctx, b);
 	return rc;
+}
+
+// B2: the per-read level of the boundary, mm_map_frag's call shape (LR/minimap.h:390; LR/map.c:1273): one fragment of n_segs segments.
+// As in the reference only segment 0 is sketched and aligned (SURVEY bug-compatibility item 7); the other segments get no records.
+extern "C" int gdiet_hip_map_frag(gdiet_ctx *ctx, const gdiet_index *ix, const gdiet_mapopt_t *opt, int n_segs, const int32_t *qlens, const char *const *seqs,
+                                  int32_t *n_regs, gdiet_reg_t **regs)
+{
+	if (!ctx || !ix || !opt || n_segs < 1 || !qlens || !seqs || !n_regs || !regs) return GDIET_E_PARAM;
+	for (int i = 0; i < n_segs; ++i) n_regs[i] = 0, regs[i] = nullptr;
+	if (qlens[0] <= 0) return GDIET_OK; // (LR/map.c:1288: qlen_sum == 0 returns without records)
+	return gdiet_hip_map_batch(ctx, ix, opt, 1, seqs, qlens, n_regs, regs);
+}
+
+// B4: the sketch / seed level of the boundary for a batch of reads -- mm_sketch2 + mm_get_shift, mm_sketch3, mm_seed_mz_flt,
+// mm_collect_matches2 (LR/mmpriv.h:65-76; LR/map.c:1296-1325) -- i.e. the output of the seeding kernel, copied out.
+extern "C" int gdiet_hip_seed_batch(gdiet_ctx *ctx, const gdiet_index *ix, const gdiet_mapopt_t *copt, int n, const char *const *seqs, const int32_t *lens,
+                                    int32_t *shift, uint32_t *tmp_extracted_len, uint32_t *n_mv, int64_t *seed_off, int64_t *occ_off, gdiet_seed_t **seeds,
+                                    uint64_t **occ)
+{
+	if (!ctx || !ix || !copt || n < 0 || (n && (!seqs || !lens)) || !shift || !tmp_extracted_len || !n_mv || !seed_off || !occ_off || !seeds || !occ) return GDIET_E_PARAM;
+	*seeds = nullptr, *occ = nullptr;
+	seed_off[0] = occ_off[0] = 0;
+	if (n == 0) return GDIET_OK;
+	(void)hipSetDevice(ctx->device);
+	for (int i = 0; i < 4; ++i)
+		if (ctx->async_busy[i]) { ctx->err = "batches submitted with gdiet_hip_map_submit are still in flight"; return GDIET_E_PARAM; }
+	GdMapOpt O;
+	gd_opt_from_c(copt, ix, O);
+	int rc = gd_check_opt(ctx, O);
+	if (rc) return rc;
+	{ std::string e; if (!gd_index_fetch_host(const_cast<gdiet_index *>(ix), e)) { ctx->err = e; return GDIET_E_HIP; } } // the occurrence lists are copied from the host tables
+	gdiet_read_batch *b = nullptr;
+	if ((rc = gdiet_hip_batch_upload(ctx, &b, n, seqs, lens))) return rc;
+	for (gdiet_ctx *c : ctx->children) gdiet_hip_destroy(c);
+	ctx->children.clear();
+	ctx->lane_threads = ctx->host_threads;
+	GdSeedExport sx;
+	GdBatchView V = {n, b->roff.data(), b->enc.data(), (const uint8_t *)b->d_reads, (const int64_t *)b->d_roff};
+	rc = gd_map_range(ctx, ix, O, V, nullptr, nullptr, &sx);
+	gdiet_hip_batch_destroy(ctx, b);
+	if (rc) return rc;
+	for (int i = 0; i < n; ++i) {
+		const MapSeedOut &o = sx.out[i];
+		shift[i] = o.shift, tmp_extracted_len[i] = o.tel, n_mv[i] = o.n_mv;
+		seed_off[i + 1] = seed_off[i] + (o.n_seeds > 0 ? o.n_seeds : 0), occ_off[i + 1] = occ_off[i] + (o.n_seeds > 0 ? o.n_a : 0);
+	}
+	gdiet_seed_t *sd = (gdiet_seed_t *)malloc(sizeof(gdiet_seed_t) * (size_t)std::max<int64_t>(seed_off[n], 1));
+	uint64_t *oc = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(occ_off[n], 1));
+	if (!sd || !oc) { free(sd), free(oc); ctx->err = "out of host memory"; return GDIET_E_NOMEM; }
+	int64_t at = 0;
+	for (int64_t j = 0; j < seed_off[n]; ++j) {
+		const GdSeed &g = sx.seeds[(size_t)j];
+		sd[j].n = g.n, sd[j].q_pos = g.q_pos;
+		for (uint32_t t = 0; t < g.n; ++t) oc[at++] = ix->h.pos[(size_t)g.start + t];
+	}
+	if (at != occ_off[n]) { free(sd), free(oc); ctx->err = "seed tables disagree"; return GDIET_E_HIP; }
+	*seeds = sd, *occ = oc;
+	return GDIET_OK;
 }
 
 extern "C" size_t gdiet_hip_sam_record(const gdiet_index *ix, const char *qname, const char *seq, const char *qual, int32_t l_seq,

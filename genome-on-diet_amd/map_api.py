@@ -72,6 +72,9 @@ def _bind(lib):
     lib.gdiet_hip_free_regs.restype = None
     lib.gdiet_hip_map_batch_multi.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(MapOpt), C.c_int, cpp, i32p, i32p, C.POINTER(C.POINTER(Reg))]
     lib.gdiet_hip_read_ranges_by_cost.argtypes = [C.c_int, i32p, C.c_int, C.c_int32, i32p]
+    lib.gdiet_hip_map_frag.argtypes = [vp, vp, C.POINTER(MapOpt), C.c_int, i32p, cpp, i32p, C.POINTER(C.POINTER(Reg))]
+    lib.gdiet_hip_seed_batch.argtypes = [vp, vp, C.POINTER(MapOpt), C.c_int, cpp, i32p, i32p, u32p, u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                         C.POINTER(vp), C.POINTER(vp)]
     lib.gdiet_hip_map_failed_reads.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]
     lib.gdiet_hip_batch_upload.argtypes = [vp, C.POINTER(vp), C.c_int, cpp, i32p]
     lib.gdiet_hip_map_uploaded.argtypes = [vp, vp, C.POINTER(MapOpt), vp, i32p, C.POINTER(C.POINTER(Reg))]
@@ -134,6 +137,32 @@ def map_multi(mappers, reads):
 
 
 class Mapper:
+    def map_frag(self, seqs):
+        """gdiet_hip_map_frag: one fragment (list of segment sequences), mm_map_frag's call shape"""
+        n, seqs_b, arr, lens = self._arrays(seqs)
+        n_regs = (C.c_int32 * n)()
+        regs = (C.POINTER(Reg) * n)()
+        self.ctx._check(self.lib.gdiet_hip_map_frag(self.ctx._h, self._idx, C.byref(self.opt), n, lens.ctypes.data_as(C.POINTER(C.c_int32)), arr, n_regs, regs))
+        return MapResult(self.lib, n, n_regs, regs)
+
+    def seed_batch(self, reads):
+        """gdiet_hip_seed_batch: per read (shift, tmp_extracted_len, n_mv, seeds [(n, q_pos)], occurrences [y values of the seeds, back to back])"""
+        n, reads_b, arr, lens = self._arrays(reads)
+        shift, tel, n_mv = np.zeros(n, np.int32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        so, oo = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        sd, oc = C.c_void_p(), C.c_void_p()
+        i32p, u32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
+        self.ctx._check(self.lib.gdiet_hip_seed_batch(self.ctx._h, self._idx, C.byref(self.opt), n, arr, lens.ctypes.data_as(i32p), shift.ctypes.data_as(i32p),
+                                                      tel.ctypes.data_as(u32p), n_mv.ctypes.data_as(u32p), so.ctypes.data_as(i64p), oo.ctypes.data_as(i64p),
+                                                      C.byref(sd), C.byref(oc)))
+        try:
+            seeds = np.ctypeslib.as_array(C.cast(sd, u32p), shape=(int(so[n]) * 2,)).reshape(-1, 2).copy() if so[n] else np.zeros((0, 2), np.uint32)
+            occ = np.ctypeslib.as_array(C.cast(oc, C.POINTER(C.c_uint64)), shape=(int(oo[n]),)).copy() if oo[n] else np.zeros(0, np.uint64)
+        finally:
+            libc = C.CDLL(None)
+            libc.free(sd), libc.free(oc)
+        return [dict(shift=int(shift[i]), tel=int(tel[i]), n_mv=int(n_mv[i]), seeds=seeds[so[i]:so[i + 1]], occ=occ[oo[i]:oo[i + 1]]) for i in range(n)]
+
     def failed_reads(self):
         """(reads the last map call left unmapped because of a degenerate DP box, the same since the context was made, description)"""
         a, b, w = C.c_int64(), C.c_int64(), C.c_char_p()

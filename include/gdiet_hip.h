@@ -258,6 +258,25 @@ int gdiet_hip_map_batch(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapo
                         const char *const *seqs, const int32_t *lens, int32_t *n_regs, gdiet_reg_t **regs);
 void gdiet_hip_free_regs(int n_reads, int32_t *n_regs, gdiet_reg_t **regs);
 
+/* B2, the per-read level of the boundary: mm_map_frag's call shape (LR/minimap.h:390, LR/map.c:1273-1940) for ONE fragment of n_segs
+ * segments.  As in the reference only segment 0 is sketched and aligned (qlen_sum aside: paired-end input is effectively unsupported
+ * there, SURVEY bug-compatibility item 7): n_regs[0] / regs[0] receive its records, the other segments none.  Release with
+ * gdiet_hip_free_regs(n_segs, n_regs, regs).  A wavefront-per-alignment device path gains nothing from one read at a time: this entry
+ * exists for callers that are written against mm_map_frag; throughput lives in gdiet_hip_map_batch / _submit. */
+int gdiet_hip_map_frag(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, int n_segs, const int32_t *qlens,
+                       const char *const *seqs, int32_t *n_regs, gdiet_reg_t **regs);
+
+/* B4, the sketch / seed level of the boundary (LR/mmpriv.h:65-76), for a batch of reads: what mm_sketch2 + mm_get_shift (the pattern phase
+ * shift[i]), mm_sketch3 (tmp_extracted_len[i]), mm_seed_mz_flt (n_mv[i]: minimizers left after the query-side filter) and
+ * mm_collect_matches2 (the kept seeds: mm_seed_t reduced to n = occurrences in the index and q_pos = lastPos<<1 | strand, in sketch
+ * order; their occurrence lists = the y values mm_idx_get returns, rid<<32 | lastPos<<1 | strand) produce for every read -- the output of
+ * the seeding kernel (LR/map.c:1296-1325).  Read i owns seeds[seed_off[i] .. seed_off[i+1]) and occ[occ_off[i] .. occ_off[i+1]) (the
+ * lists of its seeds back to back).  *seeds and *occ are malloc'd: free() them. */
+typedef struct { uint32_t n, q_pos; } gdiet_seed_t;
+int gdiet_hip_seed_batch(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_mapopt_t *opt, int n_reads, const char *const *seqs,
+                         const int32_t *lens, int32_t *shift, uint32_t *tmp_extracted_len, uint32_t *n_mv, int64_t *seed_off,
+                         int64_t *occ_off, gdiet_seed_t **seeds, uint64_t **occ);
+
 /* Reads of the most recent map call on this context that were given up on and came back unmapped (n_regs = 0) while the rest of their
  * batch was mapped: a candidate's DP box lay outside its read / contig or had wrapped to an absurd size -- input on which the
  * reference reads stale heap memory (LR/map.c:1654-1806 with mm_idx_getseq2 returning short / -1), i.e. has no defined result.
