@@ -45,6 +45,7 @@ struct gdiet_ctx {
 	hipStream_t stream_dp = nullptr;   // stream of the DP stage in an async lane (GDIET_DP_PRIORITY=1 raises its priority)
 	hipEvent_t ev2[3] = {nullptr, nullptr, nullptr}; // go, DP of the tail done, tail done
 	int dp_split = 1, wave_slots = 5120, last_split = 0;
+	int dp_waves = 5;                  // wavefronts per SIMD the 64-lane DP kernel is launched for (gdiet_hip_set_dp_waves / GDIET_DP_WAVES: 5 or 4)
 	int wide_ckpt = -1;                // GDIET_WIDE_CKPT: 1 / 0 force / forbid the checkpointed wide-band kernel, default by batch size
 	int wide_two_waves = -1;           // GDIET_WIDE_TWO_WAVES: 1 / 0 force the two-wavefront / two-blocks-per-lane kernel for wide bands, default by count
 	int vote_wave = 1;                 // GDIET_VOTE_WAVE=0: the sequential vote kernel for long reads too
@@ -227,6 +228,8 @@ extern "C" int gdiet_hip_init(gdiet_ctx **out, int device)
 		if (ib) ctx->index_on_device = strcmp(ib, "host") != 0;
 		const char *po = getenv("GDIET_POST");
 		if (po) ctx->post_on_device = strcmp(po, "host") != 0;
+		const char *dw = getenv("GDIET_DP_WAVES");
+		if (dw && atoi(dw) == 4) ctx->dp_waves = 4;
 		const char *sb = getenv("GDIET_SR_BOXES");
 		if (sb) ctx->sr_boxes_on_device = strcmp(sb, "host") != 0;
 		const char *fb = getenv("GDIET_FUSE_BT");
@@ -321,6 +324,13 @@ extern "C" int gdiet_hip_set_kernel_mode(gdiet_ctx *ctx, int mode)
 {
 	if (!ctx || mode < 0 || mode > 2) return GDIET_E_PARAM;
 	ctx->kernel_mode = mode;
+	return GDIET_OK;
+}
+
+extern "C" int gdiet_hip_set_dp_waves(gdiet_ctx *ctx, int waves_per_simd)
+{
+	if (!ctx || (waves_per_simd != 4 && waves_per_simd != 5)) return GDIET_E_PARAM;
+	ctx->dp_waves = waves_per_simd;
 	return GDIET_OK;
 }
 
@@ -679,7 +689,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	}
 	if (n64 > 0)
 		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64], n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, split ? 1 : 0, single,
-		                 fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);
+		                 fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr, ctx->parent ? ctx->parent->dp_waves : ctx->dp_waves);
 	if (split) {
 		gd_launch_wave64(d_tasks, d_ids + id_off[GD_KIND_WAVE64] + n_head, n64 - n_head, d_qseq, d_tseq, d_bt, d_status, d_score, K, ctx->stream2, 2, false,
 		                 fuse ? d_n_cigar : nullptr, fuse ? d_cigar : nullptr);

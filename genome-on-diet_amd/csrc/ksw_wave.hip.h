@@ -292,17 +292,21 @@ static inline int gd_wave64_block()
 
 static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, int n, const uint8_t *q, const uint8_t *t,
                                     uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, int tag = 0, bool single = false,
-                                    int32_t *n_cigar = nullptr, uint32_t *cigar = nullptr /* both given: fused backtrack */)
+                                    int32_t *n_cigar = nullptr, uint32_t *cigar = nullptr /* both given: fused backtrack */,
+                                    int waves_per_simd = 5 /* 4: see gdiet_hip_set_dp_waves */)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
 	// one wavefront per workgroup: a finished wavefront frees its slot at once instead of waiting for its three block mates
 	const int bs = gd_wave64_block();
 	const dim3 grid((n + bs / 64 - 1) / (bs / 64)), block(bs);
-	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0, false>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
-	else if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
-	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
-	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), grid, block, 0, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	// Four wavefronts per SIMD instead of five: the kernel uses no LDS, so an (unused) dynamic allocation of a sixteenth of the CU's 160 KB
+	// per wavefront caps the CU at 16 of them; the fifth wavefront's 96 registers per SIMD then stay free for other kernels.
+	const size_t lds = waves_per_simd == 4 ? (size_t)(160 * 1024 / 16) * (bs / 64) : 0;
+	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0, false>), grid, block, lds, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else if (tag == 1) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 1>), grid, block, lds, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else if (tag == 2) hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 2>), grid, block, lds, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
+	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<64, 0>), grid, block, lds, s, tasks, ids, n, q, t, bt, status, score, K, n_cigar, cigar);
 }
 // ids: 64 / G task ids per wavefront (identical geometry; -1 pads an incomplete group), n_groups wavefronts; G = 16, 10 or 8
 template <int G> static inline void gd_launch_wave_groups(const KswTask *tasks, const int32_t *ids, int n_groups, const uint8_t *q, const uint8_t *t,

@@ -135,6 +135,10 @@ class Context:
         self._check(self.lib.gdiet_hip_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_dp_waves(self, n):
+        self.lib.gdiet_hip_set_dp_waves.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.gdiet_hip_set_dp_waves(self._h, n))
+
     def last_dp_clock(self):
         """(median sclk MHz, min sclk MHz, median wavefront ms) of the 64-lane DP kernel's wavefronts (gdiet_hip_last_dp_clock)"""
         a, b, c = C.c_double(), C.c_double(), C.c_double()

@@ -167,6 +167,11 @@ int gdiet_hip_set_kernel_mode(gdiet_ctx *ctx, int mode);
  * alignments, one per resident wavefront slot) and a tail launch on a second stream, so that the head's backtrack overlaps the
  * tail's DP.  0: one launch, one backtrack (what bench.py uses for its roofline passes: one kernel, one duration). */
 int gdiet_hip_set_dp_split(gdiet_ctx *ctx, int on);
+/* Wavefronts per SIMD the 64-lane DP kernel (long reads) is launched for: 5 (default: 96 VGPRs, the best throughput of a full pipeline)
+ * or 4 (a fifth of every SIMD's registers stays free, so the seeding / voting kernels of the NEXT batch run beside the
+ * DP kernel instead of trickling through as its wavefronts retire -- two batches in flight then keep the DP kernels back to back, at
+ * two instead of three step times of latency; bench.py latency_mode).  Same arithmetic, same results. */
+int gdiet_hip_set_dp_waves(gdiet_ctx *ctx, int waves_per_simd);
 /* average device time (ms, HIP events on the launch stream) of the DP kernel(s) and of the backtrack kernel of the
  * most recent *_dev / host batch; only valid after the stream has been synchronised. */
 int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *backtrack_ms);

@@ -488,3 +488,26 @@ def test_golden_sam_under_the_other_post_kernel(env, kinds):
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_env_check.py")
     r = subprocess.run([sys.executable, script] + kinds, capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_dp_kernel_at_four_wavefronts_per_simd(gpu_ctx, pkg):
+    """gdiet_hip_set_dp_waves(4): the 64-lane DP kernel capped at four wavefronts per SIMD (room for the next batch's seeding / voting
+    kernels): the same records, synchronously and with two batches in flight"""
+    base, stem, preset = SETS["hifi_sv"]
+    names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+    reads = reads_of("hifi_sv")
+    want = "".join(l + "\n" for l in golden_sam("hifi_sv"))
+    m = pkg.Mapper(gpu_ctx, names, seqs, preset=preset)
+    try:
+        gpu_ctx.set_dp_waves(4)
+        assert m.sam_batch(m.map([r[1] for r in reads]), reads) == want
+        b = m.upload([r[1] for r in reads])
+        m.set_inflight(2)
+        t1, t2 = m.submit(b), m.submit(b)
+        assert m.sam_batch(m.wait(t1), reads) == want and m.sam_batch(m.wait(t2), reads) == want
+        m.free_batch(b)
+        with pytest.raises(pkg.GdietError):
+            gpu_ctx.set_dp_waves(3)
+    finally:
+        gpu_ctx.set_dp_waves(5)
+        m.close()
