@@ -489,8 +489,9 @@ def main():
     if rank == 0 and not args.no_latency_modes:
         # the same pipelined steps with fewer batches in flight: a batch then waits for fewer DP kernels ahead of it (p50 ~ depth x step)
         lat_modes = []
-        for depth, dp_waves in [(d, w) for d in sorted({2, max(1, args.inflight - 1)} - {args.inflight, 1}) for w in (5, 4)] + [(args.inflight, 4)]:
-            ctx.set_dp_waves(dp_waves)  # 4: the DP kernel leaves a fifth of every SIMD's registers to the next batch's seeding / voting kernels
+        # (gdiet_hip_set_dp_waves(4) -- a fifth of every SIMD's registers left to the next batch's seeding / voting kernels -- was measured
+        # here as well: the DP kernel loses 10 %, 762 Mbases/s at 202 ms with two batches in flight; profiles/r03_latency_modes.json)
+        for depth, dp_waves in [(d, 5) for d in sorted({2, max(1, args.inflight - 1)} - {args.inflight, 1})]:
             mapper.set_inflight(depth)
             keep, args.inflight = args.inflight, depth
             run_steps(depth)
@@ -504,7 +505,6 @@ def main():
             lat_modes.append({"reads_per_batch": len(batches[0][1]), "batches_in_flight": depth, "dp_wavefronts_per_simd": dp_waves, "steps": 16,
                               "p50_read_latency_ms": 1e3 * float(np.median(rec3["latency"])),
                               "bases_per_s": sum(rec3["mapped_bases"]) / dt4, "dp_kernel_ms_last": rec3["kern"][-1][0]})
-        ctx.set_dp_waves(5)
         mapper.set_inflight(args.inflight)
         # one batch at a time: one round of the 5 120 resident wavefront slots is ~2 780 reads (1.84 alignments per read); then smaller
         lat_modes += latency_modes(mapper, ctx, batches, [(len(batches[0][1]), 3), (2780, 4), (1024, 6), (256, 8), (32, 8)])
