@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void map_vote_kernel(int n_reads, const int64_t
 // strand's hits are sorted by target with a wavefront bitonic sort in LDS, and the whole wavefront runs the (wave-uniform) vote
 // scans in lockstep on a 64-hits-per-round-trip view of the sorted arrays.
 // A strand with more than MAP_VOTE_CAP hits is sorted in LDS-sized runs that are then merged in global memory by the whole wavefront.
-#define MAP_VOTE_CAP 4096
+#define MAP_VOTE_CAP 4096 // (the array bound; the launches use gd_vote_cap_max(): 1024 by default)
 
 // Front-to-back view of a sorted hit array for the vote scans, executed by ALL lanes of the wavefront in lockstep: the lanes
 // load 64 consecutive hits at once and hand them out through v_readlane, so the (wave-uniform, hence scalar) scan pays one LDS

@@ -369,6 +369,20 @@ struct GdBatchView {
 	const int64_t *d_roff; // device copy of roff (already offset to the slice)
 };
 
+// LDS capacities of the wave seed / vote kernels (entries; the launch sizes its dynamic LDS from them): upper bounds, lowered for A/B
+// measurements with GDIET_SEED_SORT_CAP / GDIET_VOTE_CAP -- less LDS per wavefront = more wavefronts per CU, longer lists go through the
+// kernels' global-memory paths (every path is exact)
+static int gd_sort_cap_max()
+{
+	static const int v = [] { const char *e = getenv("GDIET_SEED_SORT_CAP"); int c = e ? atoi(e) : MAP_SORT_CAP_MAX; int p = MAP_SORT_CAP; while (p < c && p < MAP_SORT_CAP_MAX) p <<= 1; return p; }();
+	return v;
+}
+static unsigned gd_vote_cap_max()
+{
+	static const unsigned v = [] { const char *e = getenv("GDIET_VOTE_CAP"); unsigned c = e ? (unsigned)atoi(e) : MAP_VOTE_CAP, p = 256; while (p < c && p < MAP_VOTE_CAP) p <<= 1; return p; }();
+	return v;
+}
+
 // B4 (gdiet_hip_seed_batch): what the seeding stage leaves, copied out right behind the seed kernel instead of going on
 struct GdSeedExport {
 	std::vector<MapSeedOut> out;   // per read: shift, tmp_extracted_len, n_mv, n_seeds, n_a
@@ -437,7 +451,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		for (int i = 0; i < n; ++i) max_len = std::max<int64_t>(max_len, B.roff[i + 1] - B.roff[i]);
 		const double est = 1.25 * 2.0 / (O.w + 1) * gd_diet_len(O.pat, (unsigned)max_len, 0);
 		int cap = MAP_SORT_CAP;
-		while (cap < MAP_SORT_CAP_MAX && cap < est) cap <<= 1;
+		while (cap < gd_sort_cap_max() && cap < est) cap <<= 1;
 		D.sort_cap = cap;
 	}
 	// Reads of very different lengths (ONT: log-normal up to 150 kbp): one launch per capacity class, each read in the class its own
@@ -452,7 +466,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		for (int i = 0; i < n; ++i) {
 			const double est = 1.25 * 2.0 / (O.w + 1) * gd_diet_len(O.pat, (unsigned)(B.roff[i + 1] - B.roff[i]), 0);
 			int cap = MAP_SORT_CAP, c = 0;
-			while (cap < MAP_SORT_CAP_MAX && cap < est) cap <<= 1, ++c;
+			while (cap < gd_sort_cap_max() && cap < est) cap <<= 1, ++c;
 			cap_of[i] = c, ++n_cls[c];
 		}
 		int used = 0;
@@ -538,7 +552,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		int64_t max_hits = 0;
 		for (int i = 0; i < n; ++i) max_hits = std::max(max_hits, hoff[i + 1] - hoff[i]);
 		unsigned vote_cap = 256;
-		while (vote_cap < MAP_VOTE_CAP && (int64_t)vote_cap < max_hits) vote_cap <<= 1;
+		while (vote_cap < gd_vote_cap_max() && (int64_t)vote_cap < max_hits) vote_cap <<= 1;
 		// the kernel also holds static LDS (its candidate list): with the full sort buffer the total passes 64 KB, which a launch is
 		// only granted after the attribute has been raised
 		if (sizeof(GdLoc) * (size_t)vote_cap + sizeof(GdVt) * GDM_MAX_VT + 64 > 64 * 1024)

@@ -162,7 +162,11 @@ def main():
     pkg = _load_pkg()
     from fixture_io import read_fasta
     ctx = pkg.Context(0)
-    names, seqs = read_fasta(a.ref)
+    if a.ref.startswith("synth:"):  # "synth:3088": bench.py's synthetic reference of that many Mbp, made in-process (no 3 GB FASTA file to write and parse)
+        import bench
+        names, seqs = bench.synth_reference(float(a.ref.split(":")[1]), seed=2)
+    else:
+        names, seqs = read_fasta(a.ref)
     t0 = time.perf_counter()
     m = pkg.Mapper(ctx, names, seqs, preset=a.preset, n_threads=pkg.effective_cpus())
     m.set_host_threads(pkg.effective_cpus())

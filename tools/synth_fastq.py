@@ -1,5 +1,6 @@
 """write a synthetic reference (FASTA) and short reads drawn from it (four-line FASTQ) for tools/map_file.py:
-    python tools/synth_fastq.py <dir> [ref_mbp=100] [n_reads=4000000] [sr|hifi]"""
+    python tools/synth_fastq.py <dir> [ref_mbp=100] [n_reads=4000000] [sr|hifi] [noref]
+(noref: only reads.fq is written; tools/map_file.py then takes "synth:<ref_mbp>" as its reference and makes the same sequences in-process)"""
 import os
 import sys
 
@@ -17,9 +18,10 @@ def main():
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 4_000_000
     os.makedirs(d, exist_ok=True)
     names, contigs = bench.synth_reference(ref_mbp, seed=2)
-    with open(os.path.join(d, "ref.fa"), "wb") as f:
-        for nm, c in zip(names, contigs):
-            f.write(b">" + nm.encode() + b"\n" + c.tobytes() + b"\n")
+    if "noref" not in sys.argv[5:]:
+        with open(os.path.join(d, "ref.fa"), "wb") as f:
+            for nm, c in zip(names, contigs):
+                f.write(b">" + nm.encode() + b"\n" + c.tobytes() + b"\n")
     kind = sys.argv[4] if len(sys.argv) > 4 else "sr"
     if kind == "hifi":
         base = min(n, 20480)
