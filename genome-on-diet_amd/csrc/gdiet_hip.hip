@@ -81,6 +81,7 @@ struct gdiet_ctx {
 	std::mutex async_mu;               // guards the ticket bookkeeping of submit / wait
 	std::vector<void *> open_tickets;  // gdiet_map_ticket* submitted and not yet waited for (joined by gdiet_hip_destroy)
 	std::vector<std::vector<uint8_t>> enc_pool; // host buffers of destroyed read batches, reused by the next uploads
+	std::vector<std::string> fmt_pool;           // chunk strings of gdiet_hip_sam_batch / _paf_batch, reused (guarded by enc_mu)
 	std::mutex enc_mu;
 	int async_next = 0, async_depth = 2;
 	bool last_was_async = false;       // gdiet_hip_last_kernel_ms then reports the lane's events, copied at gdiet_hip_map_wait

@@ -1218,23 +1218,45 @@ extern "C" size_t gdiet_hip_sam_record(const gdiet_index *ix, const char *qname,
 // All SAM records of a batch, in input order, formatted on the context's host threads (step 2 of the reference's pipeline prints
 // them one read at a time on one thread: LR/map.c:2139-2170 -> mm_write_sam3).  A read without alignments gives its unmapped
 // record; with MM_F_NO_PRINT_2ND secondary records are skipped, exactly as the reference's output loop does.
-extern "C" size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *ix, int n_reads, const char *const *qnames, const char *const *seqs,
-                                      const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
-                                      int64_t opt_flag, char **out)
+// chunk strings of the batch formatters, kept between calls (a chunk of HiFi records is megabytes: allocated fresh, every call pays
+// for its pages again -- 300 MB of first touches per 5 120-read mini-batch)
+static void gd_fmt_take(gdiet_ctx *ctx, std::vector<std::string> &rec)
 {
-	if (!ctx || !ix || n_reads < 0 || !qnames || !seqs || !lens || !n_regs || !regs || !out) return 0;
-	*out = nullptr;
-	// formatted in chunks of 512 reads (one string per chunk, not per read: a short-read batch has a quarter of a million reads, and
-	// every string made by a worker is released by this thread), then copied side by side into the output
-	const int CH = 512, n_ch = (n_reads + CH - 1) / CH;
+	std::lock_guard<std::mutex> lk(ctx->enc_mu);
+	for (std::string &r : rec) {
+		if (ctx->fmt_pool.empty()) break;
+		r.swap(ctx->fmt_pool.back()), ctx->fmt_pool.pop_back();
+		r.clear();
+	}
+}
+static void gd_fmt_give(gdiet_ctx *ctx, std::vector<std::string> &rec)
+{
+	std::lock_guard<std::mutex> lk(ctx->enc_mu);
+	for (std::string &r : rec)
+		if (ctx->fmt_pool.size() < 256 && r.capacity() > 4096) ctx->fmt_pool.emplace_back(), ctx->fmt_pool.back().swap(r);
+}
+
+// reads per chunk of the batch formatters: a few chunks per host thread, so that a mini-batch of 5 120 long reads keeps every thread busy
+// (chunks of 512 reads gave ten), but never so small that a quarter of a million short reads become tens of thousands of strings
+static int gd_fmt_chunk(const gdiet_ctx *ctx, int n_reads)
+{
+	const int want = n_reads / std::max(1, 6 * ctx->host_threads);
+	return std::max(16, std::min(512, want));
+}
+
+static size_t gd_sam_batch_impl(gdiet_ctx *ctx, const gdiet_index *ix, int n_reads, const char *const *qnames, const char *const *seqs,
+                                const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
+                                int64_t opt_flag, char **buf_io, size_t *cap_io /* null: *buf_io is malloc'd to size */)
+{
+	const int CH = gd_fmt_chunk(ctx, n_reads), n_ch = (n_reads + CH - 1) / CH;
 	std::vector<std::string> rec((size_t)n_ch);
+	gd_fmt_take(ctx, rec);
 	gd_parallel_for(ctx, ctx->host_threads, n_ch, [&](int c) {
 		static thread_local std::vector<GdReg> v; // per-thread scratch, reused from read to read
-		static thread_local std::string one;
 		std::string &s = rec[c];
 		const int i1 = std::min(n_reads, (c + 1) * CH);
 		size_t guess = 0;
-		for (int i = c * CH; i < i1; ++i) guess += 2 * (size_t)lens[i] + 160;
+		for (int i = c * CH; i < i1; ++i) guess += (2 * (size_t)lens[i] + 200) * (size_t)std::max(1, n_regs[i]);
 		s.reserve(guess);
 		for (int i = c * CH; i < i1; ++i) {
 			const int nr = n_regs[i];
@@ -1247,28 +1269,54 @@ extern "C" size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *ix, int
 				g.has_p = true, g.cigar.assign(r.cigar, r.cigar + r.n_cigar);
 			}
 			const char *q = quals ? quals[i] : nullptr;
-			if (nr <= 0) {
-				one.clear();
-				gd_write_sam(one, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, -1, opt_flag);
-				s += one, s += '\n';
-			} else
+			if (nr <= 0) gd_write_sam(s, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, -1, opt_flag), s += '\n'; // (the writer appends)
+			else
 				for (int j = 0; j < nr; ++j) {
 					if ((opt_flag & GD_F_NO_PRINT_2ND) && v[j].id != v[j].parent) continue;
-					one.clear();
-					gd_write_sam(one, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, j, opt_flag);
-					s += one, s += '\n';
+					gd_write_sam(s, ix->h.ref(), qnames[i], seqs[i], q, lens[i], v, j, opt_flag), s += '\n';
 				}
 		}
 	});
 	std::vector<size_t> at((size_t)n_ch + 1, 0);
 	for (int c = 0; c < n_ch; ++c) at[c + 1] = at[c] + rec[c].size();
 	const size_t tot = at[n_ch];
-	char *buf = (char *)malloc(tot + 1);
-	if (!buf) return 0;
+	char *buf;
+	if (cap_io) { // the caller's buffer, grown when it is too small
+		buf = *buf_io;
+		if (!buf || *cap_io < tot + 1) {
+			const size_t cap = tot + 1 + (tot >> 3);
+			char *nb = (char *)realloc(buf, cap);
+			if (!nb) { gd_fmt_give(ctx, rec); return 0; }
+			buf = nb, *buf_io = nb, *cap_io = cap;
+		}
+	} else {
+		buf = (char *)malloc(tot + 1);
+		if (!buf) { gd_fmt_give(ctx, rec); return 0; }
+		*buf_io = buf;
+	}
 	gd_parallel_for(ctx, ctx->host_threads, n_ch, [&](int c) { memcpy(buf + at[c], rec[c].data(), rec[c].size()); });
 	buf[tot] = 0;
-	*out = buf;
+	gd_fmt_give(ctx, rec);
 	return tot;
+}
+
+extern "C" size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *ix, int n_reads, const char *const *qnames, const char *const *seqs,
+                                      const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
+                                      int64_t opt_flag, char **out)
+{
+	if (!ctx || !ix || n_reads < 0 || !qnames || !seqs || !lens || !n_regs || !regs || !out) return 0;
+	*out = nullptr;
+	return gd_sam_batch_impl(ctx, ix, n_reads, qnames, seqs, quals, lens, n_regs, regs, opt_flag, out, nullptr);
+}
+
+// the same into a buffer the caller keeps from mini-batch to mini-batch (*buf / *cap: start with NULL / 0; realloc'd when too small; free()
+// it at the end): the text of a long-read mini-batch is ~150 MB, and a fresh allocation of that size is paid for page by page every time
+extern "C" size_t gdiet_hip_sam_batch_into(gdiet_ctx *ctx, const gdiet_index *ix, int n_reads, const char *const *qnames, const char *const *seqs,
+                                           const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
+                                           int64_t opt_flag, char **buf, size_t *cap)
+{
+	if (!ctx || !ix || n_reads < 0 || !qnames || !seqs || !lens || !n_regs || !regs || !buf || !cap) return 0;
+	return gd_sam_batch_impl(ctx, ix, n_reads, qnames, seqs, quals, lens, n_regs, regs, opt_flag, buf, cap);
 }
 
 // All PAF lines of a batch (mm_write_paf3, LR/format.c:326-367, as step 2 prints them when MM_F_OUT_SAM is off: LR/map.c:2163-2185).

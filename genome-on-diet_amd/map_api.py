@@ -273,6 +273,9 @@ class Mapper:
                           bw_max=p.get("bw_max", 1500), AF_max_loc=p.get("AF_max_loc", 20))
 
     def close(self):
+        if getattr(self, "_sam_buf", None) is not None and self._sam_buf.value:
+            C.CDLL(None).free(self._sam_buf)
+            self._sam_buf = C.c_void_p()
         if self._idx:
             self.lib.gdiet_hip_index_destroy(self.ctx._h, self._idx)
             self._idx = C.c_void_p()
@@ -306,19 +309,24 @@ class Mapper:
         return (h, n)
 
     def sam_batch_raw(self, res, n, names, seqs, quals, lens, sink=None):
-        """gdiet_hip_sam_batch on C arrays.  With sink (a binary file object) the text is written from the C buffer without a copy and
-        its length returned; otherwise bytes are returned."""
-        out = C.c_void_p()
+        """gdiet_hip_sam_batch on C arrays.  With sink (a binary file object) the text is formatted into a buffer kept by this mapper
+        (gdiet_hip_sam_batch_into) and written from it without a copy, and its length returned; otherwise bytes are returned."""
         cpp = C.POINTER(C.c_char_p)
+        if sink is not None:
+            if not hasattr(self, "_sam_buf"):
+                self._sam_buf, self._sam_cap = C.c_void_p(), C.c_size_t(0)
+                self.lib.gdiet_hip_sam_batch_into.restype = C.c_size_t
+                self.lib.gdiet_hip_sam_batch_into.argtypes = self.lib.gdiet_hip_sam_batch.argtypes[:-1] + [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+            m = self.lib.gdiet_hip_sam_batch_into(self.ctx._h, self._idx, n, C.cast(names, cpp), C.cast(seqs, cpp), C.cast(quals, cpp), lens, res.n_regs, res.regs,
+                                                  self.opt.flag, C.byref(self._sam_buf), C.byref(self._sam_cap))
+            if m:
+                sink.write(memoryview((C.c_char * m).from_address(self._sam_buf.value)))
+            return m
+        out = C.c_void_p()
         m = self.lib.gdiet_hip_sam_batch(self.ctx._h, self._idx, n, C.cast(names, cpp), C.cast(seqs, cpp), C.cast(quals, cpp), lens, res.n_regs, res.regs,
                                          self.opt.flag, C.byref(out))
         try:
-            if not out.value:
-                return 0 if sink is not None else b""
-            if sink is not None:
-                sink.write(memoryview((C.c_char * m).from_address(out.value)))
-                return m
-            return C.string_at(out.value, m)
+            return C.string_at(out.value, m) if out.value else b""
         finally:
             if out.value:
                 C.CDLL(None).free(C.c_void_p(out.value))

@@ -348,6 +348,13 @@ size_t gdiet_hip_sam_batch(gdiet_ctx *ctx, const gdiet_index *idx, int n_reads, 
                            const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
                            int64_t opt_flag, char **out);
 
+/* The same into a buffer the caller keeps from mini-batch to mini-batch: *buf / *cap start as NULL / 0, are realloc'd when too small, and
+ * are free()d by the caller at the end.  (The SAM text of a long-read mini-batch is ~150 MB; a fresh allocation of that size costs its
+ * page faults every time.)  Returns the length of the text. */
+size_t gdiet_hip_sam_batch_into(gdiet_ctx *ctx, const gdiet_index *idx, int n_reads, const char *const *qnames, const char *const *seqs,
+                                const char *const *quals, const int32_t *lens, const int32_t *n_regs, gdiet_reg_t *const *regs,
+                                int64_t opt_flag, char **buf, size_t *cap);
+
 /* The same for PAF output: mm_write_paf3 (LR/format.c:326-367) as step 2 prints it when MM_F_OUT_SAM is off (LR/map.c:2163-2185).
  * opt_flag: MM_F_OUT_CG (0x20, `-c`) adds the cg:Z: tag, MM_F_PAF_NO_HIT (0x8000000, --paf-no-hit) the lines of unmapped reads,
  * MM_F_NO_PRINT_2ND drops secondary records, MM_F_QSTRAND is honoured.  *out is malloc'd; returns its length. */
