@@ -8,15 +8,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401,E402  (first: one HIP runtime)
 from conftest import load_pkg  # noqa: E402
-from fixture_io import LR, golden_sam, read_fasta, read_fastq  # noqa: E402
+from fixture_io import OVERRIDES, SETS, golden_sam, read_fasta, reads_of  # noqa: E402
 
+kind = sys.argv[1] if len(sys.argv) > 1 else "hifi"  # "sr": the box stage runs on the device (map_sr_box_kernel marks the read there)
 pkg = load_pkg()
 ctx = pkg.Context(0)
-names, seqs = read_fasta(os.path.join(LR, "ref.fa.gz"))
-reads = read_fastq(os.path.join(LR, "hifi.fq.gz"))
-m = pkg.Mapper(ctx, names, seqs, preset="hifi")
+base, stem, preset = SETS[kind]
+names, seqs = read_fasta(os.path.join(base, "ref.fa.gz"))
+reads = reads_of(kind)
+m = pkg.Mapper(ctx, names, seqs, preset=preset, **OVERRIDES.get(kind, {}))
 victim = reads[int(os.environ["GDIET_FAULT_BOX"])][0]
-want = [l for l in golden_sam("hifi") if l.split("\t")[0] != victim]
+assert any(l.split("\t")[0] == victim and l.split("\t")[1] != "4" for l in golden_sam(kind)), "the victim must be a read that maps"
+want = [l for l in golden_sam(kind) if l.split("\t")[0] != victim]
 
 
 def check(res):

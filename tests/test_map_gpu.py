@@ -467,14 +467,15 @@ def test_single_process_fan_out_over_contexts(pkg, kind, n_ctx):
             c.close()
 
 
-def test_degenerate_box_fails_its_read_not_the_batch():
+@pytest.mark.parametrize("kind", ["hifi", "sr"])
+def test_degenerate_box_fails_its_read_not_the_batch(kind):
     """a read whose DP box is degenerate (fault injection, GDIET_FAULT_BOX=<read index>: no read built so far produces one) comes
     back unmapped and is counted; every other read of the batch gets its golden records -- synchronously and with a batch in flight
     (tests/fault_box_check.py, in a process of its own: the library reads the variable once)"""
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fault_box_check.py")
-    r = subprocess.run([sys.executable, script], capture_output=True, text=True, env=dict(os.environ, GDIET_FAULT_BOX="5"), timeout=600)
+    r = subprocess.run([sys.executable, script, kind], capture_output=True, text=True, env=dict(os.environ, GDIET_FAULT_BOX="5"), timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
