@@ -21,8 +21,15 @@ struct MapDevOpt { // uniform per batch
 	int32_t is_sr;
 	int32_t sort_cap;  // hashes of one read the wave seed kernel sorts in LDS (a power of two; the launch provides 8 B each)
 	uint32_t seed_lds; // dynamic LDS bytes of the wave seed kernel's launch
+	int32_t prio;      // s_setprio of the wave seed / vote kernels' wavefronts (0-3): they run beside the DP wavefronts of another batch
 	GdPattern pat;
 };
+__device__ __forceinline__ void map_set_prio(int p)
+{
+	if (p == 1) __builtin_amdgcn_s_setprio(1);
+	else if (p == 2) __builtin_amdgcn_s_setprio(2);
+	else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+}
 
 struct MapReadScratch { // per-read slices of the batch scratch arena (element offsets)
 	uint64_t mv_off;     // GdMini[mv_cap]
@@ -160,6 +167,7 @@ __global__ __launch_bounds__(64) void map_vote_wave_kernel(int n_reads, const in
                                                            GdLoc *__restrict__ hits, MapVoteOut *__restrict__ out, unsigned vote_cap)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t vote_lds[];
+	map_set_prio(O.prio);
 	GdLoc *s_buf = reinterpret_cast<GdLoc *>(vote_lds); // one strand at a time
 	const int rid = blockIdx.x;
 	if (rid >= n_reads) return;
@@ -377,6 +385,7 @@ __global__ __launch_bounds__(64) void map_sr_fill_kernel(int n_reads, const int6
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void map_pack_cigar_kernel(int nb, const uint32_t *__restrict__ cig, const int64_t *__restrict__ coff,
                                                             const int64_t *__restrict__ poff, uint32_t *__restrict__ packed)
 {
+	__builtin_amdgcn_s_setprio(3); // (see map_post_wave_kernel)
 	const int b = blockIdx.x;
 	if (b >= nb) return;
 	const int64_t n = poff[b + 1] - poff[b];
@@ -447,6 +456,7 @@ __global__ __launch_bounds__(64) void map_fix_cigar_kernel(int nb, const MapBox 
                                                            const int64_t *__restrict__ coff, uint32_t *__restrict__ cig, int32_t *__restrict__ n_cigar,
                                                            const int32_t *__restrict__ score, GdPostOut *__restrict__ post)
 {
+	__builtin_amdgcn_s_setprio(3); // (see map_post_wave_kernel)
 	const int b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= nb) return;
 	GdPostOut P;
@@ -466,6 +476,9 @@ __global__ __launch_bounds__(64) void map_post_wave_kernel(int nb, const MapBox 
                                                            int32_t *__restrict__ x_score, int32_t *__restrict__ x_ncig)
 {
 #pragma clang fp contract(off)
+	// These wavefronts run beside a full house of DP wavefronts of the next batch (older, VALU-bound, five per SIMD): at the default
+	// priority they get the issue slots those leave and the kernel's 2 ms of work took 40 ms -- the tail of every batch's latency.
+	__builtin_amdgcn_s_setprio(3);
 	const int b = blockIdx.x;
 	if (b >= nb) return;
 	const unsigned lane = threadIdx.x;
@@ -636,6 +649,7 @@ __global__ __launch_bounds__(64) void map_seed_wave_kernel(int n_reads, const ui
                                                            uint64_t *__restrict__ u64_arena, GdSeed *__restrict__ seed_arena, MapSeedOut *__restrict__ out,
                                                            const int32_t *__restrict__ ids /* the reads of this launch (null: 0 .. n_reads - 1) */)
 {
+	map_set_prio(O.prio);
 	if ((int)blockIdx.x >= n_reads) return;
 	const int rid = ids ? ids[blockIdx.x] : (int)blockIdx.x;
 	const unsigned lane = threadIdx.x;

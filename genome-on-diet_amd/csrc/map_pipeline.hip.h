@@ -446,6 +446,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	D.vote.vt_df1 = O.vt_df1, D.vote.vt_df2 = O.vt_df2, D.vote.k = O.k;
 	const bool is_sr = (O.flag & GD_F_SR) != 0;
 	D.is_sr = is_sr;
+	{ static const int side_prio = getenv("GDIET_SIDE_PRIO") ? atoi(getenv("GDIET_SIDE_PRIO")) : 0; D.prio = side_prio; }
 	{ // LDS sort capacity of the wave seed kernel: ~1.25 x the minimizers expected of the longest read (2 / (w + 1) of its sparsified bases)
 		int64_t max_len = 0;
 		for (int i = 0; i < n; ++i) max_len = std::max<int64_t>(max_len, B.roff[i + 1] - B.roff[i]);
