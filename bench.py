@@ -15,7 +15,7 @@ GPU; candidate geometry on host threads; window gather, exact-match, ksw_extd2 D
 concatenate_cigars / mm_set_sam_params on host threads) over one batch of reads that is already resident in HBM.  Every step
 maps a DIFFERENT batch: ceil(200 000 / batch) = 40 distinct batches of 5120 reads are synthesised and uploaded before the timed
 region (configs[3]'s 200 k reads; the default --steps 40 goes through each of them once, more steps cycle).  With the
-default --inflight 3 steps i+1 and i+2 are submitted (gdiet_hip_map_submit) before step i is waited for, so their seeding / voting / host
+default --inflight 2 step i+1 is submitted (gdiet_hip_map_submit) before step i is waited for, so its seeding / voting / host
 stages overlap the DP kernel of step i; all K batches are complete when the timed region ends (--inflight 1 runs them one at
 a time).  value = bases of reads with >= 1 alignment / wall time, summed over ranks (reads are sharded over GPUs, index
 replicated, no collective).  p50_read_latency_ms = median over the reads of the timed steps of (gdiet_hip_map_wait of their batch
@@ -331,8 +331,10 @@ def main():
     ap.add_argument("--ref-mbp", type=float, default=float(os.environ.get("GDIET_BENCH_REF_MBP", "3088")),
                     help="size of the synthetic reference in Mbp (default: GRCh38-sized)")
     ap.add_argument("--lanes", type=int, default=1, help="software-pipeline depth inside a step (gdiet_hip_set_map_lanes)")
-    ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4],
-                    help="batches in flight (gdiet_hip_map_submit/_wait): 2 overlaps the seeding/voting/host stages of step i+1 with the DP kernel of step i")
+    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="batches in flight (gdiet_hip_map_submit/_wait): 2 (the library's default) overlaps the seeding / voting / host stages of step i+1 with the "
+                         "DP kernel of step i -- since round 3 that keeps the DP kernels back to back (the side kernels run at a raised wave priority), at two step "
+                         "times of latency; 3 (rounds 1-2) adds a step of latency for nothing")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank maps its own --batch reads per step (the contract's default); strong = ONE read set, each "
                          "batch cut into contiguous ranges of equal DP cost (read_ranges_by_cost), one per rank")
@@ -491,18 +493,19 @@ def main():
         lat_modes = []
         # (gdiet_hip_set_dp_waves(4) -- a fifth of every SIMD's registers left to the next batch's seeding / voting kernels -- was measured
         # here as well: the DP kernel loses 10 %, 762 Mbases/s at 202 ms with two batches in flight; profiles/r03_latency_modes.json)
-        for depth, dp_waves in [(d, 5) for d in sorted({2, max(1, args.inflight - 1)} - {args.inflight, 1})]:
+        for depth, dp_waves in [(d, 5) for d in sorted({2, 3} - {args.inflight})]:
             mapper.set_inflight(depth)
             keep, args.inflight = args.inflight, depth
             run_steps(depth)
             rec3 = {k: [] for k in rec}
             torch.cuda.synchronize(dev)
             t4 = time.perf_counter()
-            run_steps(16, rec3)
+            run_steps(24, rec3)
             torch.cuda.synchronize(dev)
             dt4 = time.perf_counter() - t4
             args.inflight = keep
-            lat_modes.append({"reads_per_batch": len(batches[0][1]), "batches_in_flight": depth, "dp_wavefronts_per_simd": dp_waves, "steps": 16,
+            lat_modes.append({"reads_per_batch": len(batches[0][1]), "batches_in_flight": depth, "dp_wavefronts_per_simd": dp_waves, "steps": 24,
+                              "note": "24 steps incl. the fill and drain of the pipeline (one DP kernel's time extra: the rate of a long run is ~4 % higher)",
                               "p50_read_latency_ms": 1e3 * float(np.median(rec3["latency"])),
                               "bases_per_s": sum(rec3["mapped_bases"]) / dt4, "dp_kernel_ms_last": rec3["kern"][-1][0]})
         mapper.set_inflight(args.inflight)

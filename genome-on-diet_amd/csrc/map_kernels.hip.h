@@ -297,6 +297,7 @@ struct MapBox {
 __global__ __launch_bounds__(64) void map_gather_kernel(int n_box, const MapBox *__restrict__ boxes, const uint8_t *__restrict__ reads,
                                                         const uint32_t *__restrict__ S, uint8_t *__restrict__ qbuf, uint8_t *__restrict__ tbuf)
 {
+	__builtin_amdgcn_s_setprio(3); // (a short kernel between a batch's voting and its DP stage, beside another batch's DP wavefronts)
 	const int b = blockIdx.x;
 	if (b >= n_box) return;
 	const MapBox B = boxes[b];

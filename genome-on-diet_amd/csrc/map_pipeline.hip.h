@@ -446,7 +446,12 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	D.vote.vt_df1 = O.vt_df1, D.vote.vt_df2 = O.vt_df2, D.vote.k = O.k;
 	const bool is_sr = (O.flag & GD_F_SR) != 0;
 	D.is_sr = is_sr;
-	{ static const int side_prio = getenv("GDIET_SIDE_PRIO") ? atoi(getenv("GDIET_SIDE_PRIO")) : 0; D.prio = side_prio; }
+	// The seeding / voting wavefronts of a batch run beside the DP wavefronts of the batch before it (five per SIMD, VALU-bound, older): at
+	// the default priority they get the issue slots those leave, hold their scarce slots for a long time, and the batch is ready only when
+	// that DP kernel ends -- with two batches in flight the next DP kernel then starts ~5 ms late (834 Mbases/s).  At s_setprio(2) they are
+	// through in ~60 ms, the DP kernels follow each other back to back with TWO batches in flight (875-881 Mbases/s) and a batch spends two
+	// step times in the pipeline instead of three (p50 174 instead of 261 ms).  GDIET_SIDE_PRIO=0..3 for A/B runs.
+	{ static const int side_prio = getenv("GDIET_SIDE_PRIO") ? atoi(getenv("GDIET_SIDE_PRIO")) : 2; D.prio = side_prio; }
 	{ // LDS sort capacity of the wave seed kernel: ~1.25 x the minimizers expected of the longest read (2 / (w + 1) of its sparsified bases)
 		int64_t max_len = 0;
 		for (int i = 0; i < n; ++i) max_len = std::max<int64_t>(max_len, B.roff[i + 1] - B.roff[i]);
