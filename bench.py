@@ -488,7 +488,7 @@ def main():
     check = self_check(res, res1, batches[res_bi][1])
     del res1
     lat_modes = None
-    if rank == 0 and not args.no_latency_modes:
+    if rank == 0 and world == 1 and not args.no_latency_modes:  # (one rank only: the other ranks of a multi-GPU run would wait in the final reduction meanwhile)
         # the same pipelined steps with fewer batches in flight: a batch then waits for fewer DP kernels ahead of it (p50 ~ depth x step)
         lat_modes = []
         # (gdiet_hip_set_dp_waves(4) -- a fifth of every SIMD's registers left to the next batch's seeding / voting kernels -- was measured
