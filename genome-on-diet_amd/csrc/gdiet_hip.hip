@@ -29,35 +29,6 @@ struct DevBuf {
 	size_t cap = 0;
 };
 
-// Host buffer of a read batch's encoded bases, page-locked (hipHostRegister) once it has its size: the 77 MB host-to-device copy of a long-read
-// mini-batch then goes through the copy engines instead of a staging loop whose copy kernels have to find free wavefront slots beside a DP
-// kernel -- 3.4 ms of every step with the reads handed over as host buffers.  The buffers are pooled (gdiet_ctx::enc_pool), so the
-// registration is paid a few times per process.  If the registration fails the buffer simply stays pageable.
-struct GdPinnedBuf {
-	std::vector<uint8_t> v;
-	void *reg = nullptr;
-	GdPinnedBuf() = default;
-	GdPinnedBuf(const GdPinnedBuf &) = delete;
-	GdPinnedBuf &operator=(const GdPinnedBuf &) = delete;
-	GdPinnedBuf(GdPinnedBuf &&o) noexcept : v(std::move(o.v)), reg(o.reg) { o.reg = nullptr; }
-	GdPinnedBuf &operator=(GdPinnedBuf &&o) noexcept { release(); v = std::move(o.v), reg = o.reg, o.reg = nullptr; return *this; }
-	~GdPinnedBuf() { release(); }
-	void release() { if (reg) { (void)hipHostUnregister(reg); reg = nullptr; } }
-	void swap(GdPinnedBuf &o) { v.swap(o.v); std::swap(reg, o.reg); }
-	void ensure(size_t n) // at least n bytes; contents are not kept
-	{
-		if (v.size() >= n) return;
-		release();
-		v.resize(n + (n >> 3));
-		static const bool no_pin = getenv("GDIET_PIN_READS") && atoi(getenv("GDIET_PIN_READS")) == 0;
-		if (!no_pin && hipHostRegister(v.data(), v.size(), hipHostRegisterDefault) == hipSuccess) reg = v.data();
-		else (void)hipGetLastError();
-	}
-	uint8_t *data() { return v.data(); }
-	const uint8_t *data() const { return v.data(); }
-	size_t size() const { return v.size(); }
-};
-
 struct gdiet_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -109,7 +80,7 @@ struct gdiet_ctx {
 	bool async_busy[4] = {false, false, false, false};
 	std::mutex async_mu;               // guards the ticket bookkeeping of submit / wait
 	std::vector<void *> open_tickets;  // gdiet_map_ticket* submitted and not yet waited for (joined by gdiet_hip_destroy)
-	std::vector<GdPinnedBuf> enc_pool; // host buffers of destroyed read batches, reused by the next uploads
+	std::vector<std::vector<uint8_t>> enc_pool; // host buffers of destroyed read batches, reused by the next uploads
 	std::vector<std::string> fmt_pool;           // chunk strings of gdiet_hip_sam_batch / _paf_batch, reused (guarded by enc_mu)
 	std::mutex enc_mu;
 	int async_next = 0, async_depth = 2;

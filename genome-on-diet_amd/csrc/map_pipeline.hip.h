@@ -29,7 +29,7 @@ struct gdiet_index {
 struct gdiet_read_batch {
 	int n = 0;
 	std::vector<int64_t> roff;          // n+1
-	GdPinnedBuf enc;                    // nt4, forward strand, all reads packed (host copy for post-processing; page-locked: gdiet_hip.hip)
+	std::vector<uint8_t> enc;           // nt4, forward strand, all reads packed (host copy for post-processing)
 	void *d_reads = nullptr, *d_roff = nullptr;
 };
 
@@ -226,7 +226,7 @@ extern "C" int gdiet_hip_batch_upload(gdiet_ctx *ctx, gdiet_read_batch **out, in
 		std::lock_guard<std::mutex> lk(ctx->enc_mu);
 		if (!ctx->enc_pool.empty()) b->enc.swap(ctx->enc_pool.back()), ctx->enc_pool.pop_back();
 	}
-	b->enc.ensure(enc_len);
+	if (b->enc.size() < enc_len) b->enc.resize(enc_len + (enc_len >> 3));
 	t_[1] = gd_now();
 	gd_parallel_for(ctx, ctx->host_threads, n, [&](int i) {
 		if (lens[i] > 0) gd_nt4_encode(seqs[i], b->enc.data() + b->roff[i], (size_t)lens[i]);
