@@ -699,9 +699,12 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		GD_HIP(hipEventRecord(ctx->ev2[2], ctx->stream2));
 	}
 	if (!ids[GD_KIND_WAVE16].empty()) {
-		gd_launch_wave_groups<16>(d_tasks, d_ids + group_off[0], (int)(groups[0].size() / 4), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
-		gd_launch_wave_groups<10>(d_tasks, d_ids + group_off[1], (int)(groups[1].size() / 6), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
-		gd_launch_wave_groups<8>(d_tasks, d_ids + group_off[2], (int)(groups[2].size() / 8), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
+		static const bool fuse_groups = !(getenv("GDIET_FUSE_BT_GROUPS") && atoi(getenv("GDIET_FUSE_BT_GROUPS")) == 0); // (A/B switch)
+		int32_t *g_nc = fuse && fuse_groups ? d_n_cigar : nullptr;
+		uint32_t *g_cg = fuse && fuse_groups ? d_cigar : nullptr;
+		gd_launch_wave_groups<16>(d_tasks, d_ids + group_off[0], (int)(groups[0].size() / 4), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
+		gd_launch_wave_groups<10>(d_tasks, d_ids + group_off[1], (int)(groups[1].size() / 6), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
+		gd_launch_wave_groups<8>(d_tasks, d_ids + group_off[2], (int)(groups[2].size() / 8), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
 	}
 	if (!ids[GD_KIND_WAVE128].empty()) {
 		// few wide-band alignments (the arena bounds how many 50 kbp ONT alignments fit): two wavefronts share one, halving the

@@ -54,36 +54,17 @@ __global__ __launch_bounds__(64) void ksw_exact_match_kernel(const KswTask *__re
 	status[tid] = st;
 }
 
-__global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__restrict__ tasks, int n,
-                                                           const uint8_t *__restrict__ bt,
-                                                           const int32_t *__restrict__ status,
-                                                           int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
-                                                           uint32_t *__restrict__ cigar, int spread, const int32_t *__restrict__ task_ids,
-                                                           const int32_t *__restrict__ start = nullptr /* (i0, j0) per task; default: the last cell */)
+// ksw_backtrack (SR/ksw2.h:131-163) of one alignment by ONE THREAD, from cell (i, j): the body of ksw_backtrack_kernel, and the tail of
+// the short-alignment DP kernels, whose group leaders walk their own alignments back (ksw_wave.hip.h)
+__device__ __forceinline__ void gd_bt_thread_walk(const KswTask &T, int tid, const uint8_t *__restrict__ bt, int32_t *__restrict__ n_cigar,
+                                                  uint32_t *__restrict__ cigar, int i, int j)
 {
-	// spread = 1: one alignment per WAVEFRONT (lane 0 walks, the other lanes idle).  Kept for experiments only: it measured 2x
-	// SLOWER than one walk per thread, whose 64 x 16 prefetched loads per wavefront hide the latency better.
-	int tid = blockIdx.x * blockDim.x + threadIdx.x;
-	if (spread) {
-		if (threadIdx.x & 63) return;
-		tid >>= 6;
-	}
-	if (tid >= n) return;
-	if (task_ids) { tid = task_ids[tid]; if (tid < 0) return; } // a sub-list of the batch (-1: padding of a 16-lane quartet)
-	const int st = status[tid];
-	if (st == GD_ST_EXACT || st == GD_ST_TRACED) return;
-	if (st != GD_ST_DONE) { // band emptied (zdropped): no CIGAR, score stays KSW_NEG_INF (SR/ksw2_extd2_sse.c:142-145,391)
-		n_cigar[tid] = 0;
-		if (st == GD_ST_ZDROPPED) score[tid] = GD_NEG_INF;
-		return;
-	}
-	const KswTask T = tasks[tid];
 	const int qlen = T.qlen, tlen = T.tlen;
 	const int w = T.w < 0 ? (tlen > qlen ? tlen : qlen) : T.w;
 	const uint8_t *p = bt + T.bt_off;
 	uint32_t *cg = cigar + T.cig_off;
 	const int cap = T.cig_cap;
-	int nc = 0, i = start ? start[2 * tid] : tlen - 1, j = start ? start[2 * tid + 1] : qlen - 1, state = 0;
+	int nc = 0, state = 0;
 	uint32_t last = 0; // the op run being extended (kept in a register, flushed on change)
 	int have = 0;
 #define GD_PUSH(op_, len_)                                                       \
@@ -148,6 +129,33 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 			const uint32_t t0 = cg[k];
 			cg[k] = cg[nc - 1 - k], cg[nc - 1 - k] = t0;
 		}
+}
+
+__global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__restrict__ tasks, int n,
+                                                           const uint8_t *__restrict__ bt,
+                                                           const int32_t *__restrict__ status,
+                                                           int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
+                                                           uint32_t *__restrict__ cigar, int spread, const int32_t *__restrict__ task_ids,
+                                                           const int32_t *__restrict__ start = nullptr /* (i0, j0) per task; default: the last cell */)
+{
+	// spread = 1: one alignment per WAVEFRONT (lane 0 walks, the other lanes idle).  Kept for experiments only: it measured 2x
+	// SLOWER than one walk per thread, whose 64 x 16 prefetched loads per wavefront hide the latency better.
+	int tid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (spread) {
+		if (threadIdx.x & 63) return;
+		tid >>= 6;
+	}
+	if (tid >= n) return;
+	if (task_ids) { tid = task_ids[tid]; if (tid < 0) return; } // a sub-list of the batch (-1: padding of a 16-lane quartet)
+	const int st = status[tid];
+	if (st == GD_ST_EXACT || st == GD_ST_TRACED) return;
+	if (st != GD_ST_DONE) { // band emptied (zdropped): no CIGAR, score stays KSW_NEG_INF (SR/ksw2_extd2_sse.c:142-145,391)
+		n_cigar[tid] = 0;
+		if (st == GD_ST_ZDROPPED) score[tid] = GD_NEG_INF;
+		return;
+	}
+	const KswTask T = tasks[tid];
+	gd_bt_thread_walk(T, tid, bt, n_cigar, cigar, start ? start[2 * tid] : T.tlen - 1, start ? start[2 * tid + 1] : T.qlen - 1);
 }
 
 // K2 for long alignments: one WAVEFRONT per walk.  All 64 lanes fetch the next 64 cells of the current diagonal at once (one

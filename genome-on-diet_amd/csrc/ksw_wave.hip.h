@@ -270,7 +270,7 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 	}
 	// The 64-lane form (one alignment per wavefront) walks its own alignment back right away when given the CIGAR buffers: the
 	// walk is latency-bound and overlaps the DP of the other resident wavefronts, instead of a separate pass after the last one.
-	const bool fuse = LANES == 64 && cigar != nullptr;
+	const bool fuse = cigar != nullptr; // (the grouped forms: given the CIGAR buffers, every group's first lane walks its alignment back, below)
 	if (LANES == 64 && lane == 0) // (the DP rows only: the walk below is latency-bound)
 		gd_clock_stamps[(tid & (GD_CLOCK_SLOTS - 1)) * 4 + 2] = __builtin_amdgcn_s_memtime(), gd_clock_stamps[(tid & (GD_CLOCK_SLOTS - 1)) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 	if (L.blk == mlast && live) {
@@ -279,7 +279,14 @@ void ksw_extd2_wave_kernel(const KswTask *__restrict__ tasks,
 	}
 	if (fuse) {
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // this wavefront's own backtrace stores: complete, and not served from a stale L1 line
-		gd_bt_wave_walk(*Tp, tid, bt, n_cigar, cigar, lane);
+		if (LANES == 64) gd_bt_wave_walk(*Tp, tid, bt, n_cigar, cigar, lane);
+		else if (live && sub == 0) {
+			// short alignments, several per wavefront: one walk per group on its first lane -- a few hundred dependent steps through bytes
+			// the wavefront has just written, while the SIMD's other wavefronts are in their DP rows; no separate backtrack pass after
+			// the last DP wavefront (ksw_backtrack_kernel: 1.6-2.1 ms per 262 144 short reads)
+			const KswTask T = *Tp;
+			gd_bt_thread_walk(T, tid, bt, n_cigar, cigar, T.tlen - 1, T.qlen - 1);
+		}
 	}
 }
 
@@ -310,13 +317,14 @@ static inline void gd_launch_wave64(const KswTask *tasks, const int32_t *ids, in
 }
 // ids: 64 / G task ids per wavefront (identical geometry; -1 pads an incomplete group), n_groups wavefronts; G = 16, 10 or 8
 template <int G> static inline void gd_launch_wave_groups(const KswTask *tasks, const int32_t *ids, int n_groups, const uint8_t *q, const uint8_t *t,
-                                                          uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, bool single = false)
+                                                          uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, bool single = false,
+                                                          int32_t *n_cigar = nullptr, uint32_t *cigar = nullptr /* both given: fused backtrack */)
 {
 	WaveK K;
 	gdw_make_consts(C, K);
 	if (n_groups <= 0) return;
-	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<G, 0, false>), dim3((n_groups + 3) / 4), dim3(256), 0, s, tasks, ids, n_groups, q, t, bt, status, score, K, (int32_t *)nullptr, (uint32_t *)nullptr);
-	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<G, 0>), dim3((n_groups + 3) / 4), dim3(256), 0, s, tasks, ids, n_groups, q, t, bt, status, score, K, (int32_t *)nullptr, (uint32_t *)nullptr);
+	if (single) hipLaunchKernelGGL((ksw_extd2_wave_kernel<G, 0, false>), dim3((n_groups + 3) / 4), dim3(256), 0, s, tasks, ids, n_groups, q, t, bt, status, score, K, n_cigar, cigar);
+	else hipLaunchKernelGGL((ksw_extd2_wave_kernel<G, 0>), dim3((n_groups + 3) / 4), dim3(256), 0, s, tasks, ids, n_groups, q, t, bt, status, score, K, n_cigar, cigar);
 }
 
 // ---- wide bands (ONT, w = 1300): 128 blocks in flight, TWO per lane ------------------------------------------------------
