@@ -699,7 +699,11 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		GD_HIP(hipEventRecord(ctx->ev2[2], ctx->stream2));
 	}
 	if (!ids[GD_KIND_WAVE16].empty()) {
-		static const bool fuse_groups = !(getenv("GDIET_FUSE_BT_GROUPS") && atoi(getenv("GDIET_FUSE_BT_GROUPS")) == 0); // (A/B switch)
+		// The short-alignment kernels CAN walk their own alignments back (every group's first lane, gd_bt_thread_walk), but it does not pay:
+		// a wavefront then holds its slot for a few hundred dependent steps of six lanes -- DP kernel 7.6 -> 10.8 ms per 262 144 short reads
+		// against 1.65 ms of the separate backtrack kernel it saves (17.9 -> 15.1 M reads/s whole path; K3 alone 35.5 -> 26.6 M pairs/s).
+		// GDIET_FUSE_BT_GROUPS=1 switches it on (same results: the GPU suite passes either way).
+		static const bool fuse_groups = getenv("GDIET_FUSE_BT_GROUPS") && atoi(getenv("GDIET_FUSE_BT_GROUPS")) != 0;
 		int32_t *g_nc = fuse && fuse_groups ? d_n_cigar : nullptr;
 		uint32_t *g_cg = fuse && fuse_groups ? d_cigar : nullptr;
 		gd_launch_wave_groups<16>(d_tasks, d_ids + group_off[0], (int)(groups[0].size() / 4), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
