@@ -428,7 +428,10 @@ GDW_HD int gdw_track_to_slot(const WaveLane &L, int sl)
 // The wave kernel takes an alignment iff (a) every anti-diagonal fits `lanes` blocks incl. the score-row spill,
 // (b) the band never empties, (c) each block's tracker can be seeded from the block below when it enters the band
 // and the final cell can be reached from cell 0 of the last block (the band must be >= 17 cells wide there).
-static inline bool gd_wave_geometry_ok(int qlen, int tlen, int w, int lanes)
+// The definition: condition (c) block by block (~5.6 us for a 50 kbp alignment -- 70 ms of one thread per ONT mini-batch when the planner
+// asked it for every alignment).  Kept as the reference form of gd_wave_geometry_ok below; tests/emul/plan_test.cpp compares the two on
+// millions of random geometries.
+static inline bool gd_wave_geometry_ok_loop(int qlen, int tlen, int w, int lanes)
 {
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
 	if (qlen < 1 || tlen < 1) return false;
@@ -443,6 +446,41 @@ static inline bool gd_wave_geometry_ok(int qlen, int tlen, int w, int lanes)
 		gd_band(rs, qlen, tlen, w, s0, e0);
 		if (e0 != 16 * m || s0 > 16 * (m - 1)) return false;
 	}
+	{
+		int rb = tlen - 1 > 2 * (tlen - 1) - w ? tlen - 1 : 2 * (tlen - 1) - w; // first anti-diagonal with en0 == tlen-1
+		int s0, e0;
+		gd_band(rb, qlen, tlen, w, s0, e0);
+		if (e0 != tlen - 1 || s0 > 16 * mlast) return false;
+	}
+	return true;
+}
+
+// The same in O(1): as functions of the block index m, rs = max(16 m, 32 m - w), the three terms of en0 = min(tlen - 1, rs, (rs + w) >> 1)
+// and the three of st0 = max(0, rs - qlen + 1, (rs - w + 1) >> 1) are (floors of) linear functions with breakpoints only where two of them
+// cross -- m = w / 16 (rs changes its form), rs = 2 qlen - w - 1 (the two non-constant terms of st0) -- so each of the two conditions,
+// an inequality between such a function and 16 m / 16 (m - 1), can only change its truth value next to a breakpoint or at an end of
+// [1, mlast]: it is enough to test a few m around each.
+static inline bool gd_wave_geometry_ok(int qlen, int tlen, int w, int lanes)
+{
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	if (qlen < 1 || tlen < 1) return false;
+	if (gd_ncol16(qlen, tlen, w) > lanes) return false;
+	if (w < 1 || tlen - qlen > w || qlen - tlen > w) return false;
+	const int mlast = (tlen - 1) >> 4;
+	auto block_ok = [&](int m) -> bool {
+		if (m < 1 || m > mlast) return true;
+		const int rs = 16 * m > 32 * m - w ? 16 * m : 32 * m - w;
+		int s0, e0;
+		gd_band(rs, qlen, tlen, w, s0, e0);
+		return e0 == 16 * m && s0 <= 16 * (m - 1);
+	};
+	const int rx = 2 * qlen - w - 1; // the anti-diagonal on which r - qlen + 1 overtakes (r - w + 1) >> 1
+	const int around[4] = {w >> 4, rx > 0 ? (rx + w) / 32 : 0, rx > 0 ? rx / 16 : 0, mlast - 1};
+	for (int a = 0; a < 4; ++a)
+		for (int d = -2; d <= 2; ++d)
+			if (!block_ok(around[a] + d)) return false;
+	for (int m = 1; m <= 3; ++m)
+		if (!block_ok(m)) return false;
 	{
 		int rb = tlen - 1 > 2 * (tlen - 1) - w ? tlen - 1 : 2 * (tlen - 1) - w; // first anti-diagonal with en0 == tlen-1
 		int s0, e0;
