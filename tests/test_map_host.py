@@ -29,12 +29,34 @@ def host_driver(tmp_path_factory):
 
 
 THREADS = ["-t", str(min(8, os.cpu_count() or 1))]
+REP_KINDS = ("hifi_rep", "ont_rep", "sr_rep", "sr_rep_f60")
+_rep_cache = {}
+
+
+def _rep_run(host_driver, kind, tmp_path):
+    """(SAM lines, stderr) of ONE run of the host driver on a repeat-rich set, with --print-seeds --stats: the golden-SAM, stage-trace
+    and branch-count tests of these sets share it (a run is 10-15 s: the oracle's scalar DP on reads with tens of thousands of seed hits)"""
+    if kind not in _rep_cache:
+        exe, d = host_driver
+        fq = str(tmp_path / "reads.fq")
+        with open(fq, "w") as f:
+            for name, seq, qual in reads_of(kind):
+                f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
+        out = subprocess.run([exe] + THREADS + cmd_of(kind) + ["--print-seeds", "--stats", os.path.join(d, "rep", "ref.fa"), fq], capture_output=True, text=True, check=True)
+        _rep_cache[kind] = (out.stdout.rstrip("\n").split("\n"), out.stderr)
+    return _rep_cache[kind]
 
 
 @pytest.mark.parametrize("kind", ["hifi", "ont", "sr", "sr_var", "hifi_w1", "hifi_edge", "ont_edge", "sr_edge", "hifi_sv", "ont_sv", "hifi_rep", "ont_rep", "sr_rep", "sr_rep_f60"])
 def test_host_path_matches_golden_sam(host_driver, kind, tmp_path):
     exe, d = host_driver
     base = SETS[kind][0]
+    if kind in REP_KINDS:
+        got, want = _rep_run(host_driver, kind, tmp_path)[0], golden_sam(kind)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a == b, (a[:200], b[:200])
+        return
     fq = str(tmp_path / "reads.fq")
     with open(fq, "w") as f:
         for name, seq, qual in reads_of(kind):
@@ -162,10 +184,13 @@ def test_stage_trace_matches_the_reference(host_driver, tmp_path, kind):
     ref_fa = os.path.join(d, os.path.basename(SETS[kind][0]), "ref.fa")
     fq = str(tmp_path / "reads.fq")
     reads = reads_of(kind)
-    with open(fq, "w") as f:
-        for name, seq, qual in reads:
-            f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
-    err = subprocess.run([exe] + THREADS + cmd_of(kind) + ["--print-seeds", ref_fa, fq], capture_output=True, text=True, check=True).stderr
+    if kind in REP_KINDS:
+        err = _rep_run(host_driver, kind, tmp_path)[1]
+    else:
+        with open(fq, "w") as f:
+            for name, seq, qual in reads:
+                f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
+        err = subprocess.run([exe] + THREADS + cmd_of(kind) + ["--print-seeds", ref_fa, fq], capture_output=True, text=True, check=True).stderr
     mine = [l for l in err.split("\n") if l.startswith(TRACE_PREFIXES)]
     want, got = _split_trace(trace_of(kind)), _split_trace(digest_sd(mine) if kind in SD_DIGESTED else mine)
     assert len(want) == len(got) == len(reads)
@@ -191,12 +216,7 @@ def test_rep_fixtures_reach_the_high_occurrence_branches(host_driver, tmp_path, 
     """the repeat-rich sets exist to make the high-occurrence branches of the seeding stage fire; count them (and the index keys
     above mid_occ / max_max_occ) with the product's own stage code on the host"""
     import re
-    exe, d = host_driver
-    fq = str(tmp_path / "reads.fq")
-    with open(fq, "w") as f:
-        for name, seq, qual in reads_of(kind):
-            f.write("@%s\n%s\n+\n%s\n" % (name, seq, qual))
-    err = subprocess.run([exe] + THREADS + cmd_of(kind) + ["--stats", os.path.join(d, "rep", "ref.fa"), fq], capture_output=True, text=True, check=True).stderr
+    err = _rep_run(host_driver, kind, tmp_path)[1]
     st = dict(re.findall(r"([a-z_>0-9()]+)=(\d+)", " ".join(l for l in err.split("\n") if l.startswith("[stats]"))))
     num = {k.split("(")[0]: int(v) for k, v in st.items()}
     assert num["keys>mid_occ"] >= 5 and num["keys>max_max_occ"] >= 3 and num["multi"] >= 2000 and num["max_count"] > 4095
