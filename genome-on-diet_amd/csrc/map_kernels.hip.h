@@ -47,10 +47,44 @@ struct MapSeedOut {
 	int64_t n_a;      // total occurrences of the kept seeds
 };
 
+// mm_sketch2 / mm_sketch3 of one read by one thread with the winnowing window in LDS (entry j of this thread's window at win[j * 64]): the
+// bodies of gd_sketch2 / gd_sketch3 (map_stages.h) around the EXT_WIN form of the automaton.  As a local array the window is 1 KB of
+// scratch memory per thread and every window access a scratch load / store.
+__device__ __forceinline__ unsigned map_sketch2_lds(const uint8_t *str, int len, int w, int k, const GdPattern &P, float max_seeds, GdMini *out, unsigned max_out,
+                                                    uint32_t *shift_n, GdMini *win)
+{
+	unsigned len_crop, total = 0;
+	uint32_t cap;
+	if (max_seeds < 1) len_crop = (unsigned)((float)max_seeds * len), cap = UINT32_MAX;
+	else len_crop = len, cap = (uint32_t)max_seeds;
+	for (int shift = 0; shift < P.W; ++shift) {
+		const unsigned dl = gd_diet_len(P, len_crop, shift);
+		GdEmitCount e = {out + total, 0, cap, max_out - total, false};
+		gd_sketch_range<GdEmitCount, true>(str, 0, 0, dl, 0, true, w, k, 0, (unsigned)shift, P, true, e, win, 64);
+		if (e.overflow) return ~0u;
+		shift_n[shift] = e.n;
+		total += e.n;
+		if (cap == UINT32_MAX) len_crop = len, cap = e.n;
+	}
+	return total;
+}
+__device__ __forceinline__ unsigned map_sketch3_lds(const uint8_t *str, unsigned len, int w, int k, const GdPattern &P, int shift, uint32_t max_nb_seeds, GdMini *out,
+                                                    unsigned max_out, unsigned *n_out, GdMini *win)
+{
+	if (shift < 0) shift = 0;
+	const unsigned dl = gd_diet_len(P, len, (unsigned)shift);
+	GdEmitCap e = {out, 0, max_nb_seeds, max_out, len, false};
+	gd_sketch_range<GdEmitCap, true>(str, 0, 0, dl, 0, true, w, k, 0, (unsigned)shift, P, true, e, win, 64);
+	*n_out = e.overflow ? ~0u : e.n;
+	return e.ret;
+}
+
 __global__ __launch_bounds__(64) void map_seed_kernel(int n_reads, const uint8_t *__restrict__ reads, const int64_t *__restrict__ roff,
                                                       GdIdxView I, MapDevOpt O, const MapReadScratch *__restrict__ sc, GdMini *__restrict__ mv_arena,
                                                       uint64_t *__restrict__ u64_arena, GdSeed *__restrict__ seed_arena, MapSeedOut *__restrict__ out)
 {
+	extern __shared__ __attribute__((aligned(16))) uint8_t seed_thread_lds[]; // the 64 threads' winnowing windows, w x 64 entries, thread-interleaved
+	GdMini *win = reinterpret_cast<GdMini *>(seed_thread_lds) + threadIdx.x;
 	const int rid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (rid >= n_reads) return;
 	const uint8_t *str = reads + roff[rid];
@@ -61,11 +95,11 @@ __global__ __launch_bounds__(64) void map_seed_kernel(int n_reads, const uint8_t
 	const MapReadScratch S = sc[rid];
 	GdMini *mv = mv_arena + S.mv_off;
 	uint32_t shift_n[64];
-	const unsigned tot = gd_sketch2(str, len, O.w, O.k, O.pat, O.max_seeds, mv, S.mv_cap, shift_n);
+	const unsigned tot = map_sketch2_lds(str, len, O.w, O.k, O.pat, O.max_seeds, mv, S.mv_cap, shift_n, win);
 	if (tot == ~0u) { o.n_seeds = -1; out[rid] = o; return; }
 	o.shift = (int32_t)gd_get_shift(I, mv, shift_n, O.pat.W);
 	unsigned n_mv = 0;
-	o.tel = gd_sketch3(str, (unsigned)len, O.w, O.k, O.pat, o.shift, O.max_nb_seeds, mv, S.mv_cap, &n_mv);
+	o.tel = map_sketch3_lds(str, (unsigned)len, O.w, O.k, O.pat, o.shift, O.max_nb_seeds, mv, S.mv_cap, &n_mv, win);
 	if (n_mv == ~0u) { o.n_seeds = -1; out[rid] = o; return; }
 	if (O.q_occ_frac > 0.0f) n_mv = gd_mz_flt(mv, n_mv, O.mid_occ, O.q_occ_frac, u64_arena + S.u64_off);
 	o.n_mv = n_mv;

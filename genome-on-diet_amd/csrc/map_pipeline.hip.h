@@ -501,7 +501,7 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 		// one read per thread (the plain sequential form) for short reads -- a 150 bp read has ~75 sparsified bases, far too few to
 		// split over 64 lanes (measured 18x faster at 150 bp) -- and on request (GDIET_SEED_KERNEL=thread) for A/B checks
 		if (ctx->seed_thread_kernel == 1 || (ctx->seed_thread_kernel == 0 && (B.roff[n] - B.roff[0]) / n < 1024))
-			hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
+			hipLaunchKernelGGL(map_seed_kernel, dim3((n + 63) / 64), dim3(64), (size_t)O.w * 64 * sizeof(GdMini), s, n, d_reads, d_roff, ix->dview, D, (const MapReadScratch *)ctx->m_sc.p,
 			                   (GdMini *)ctx->m_mv.p, (uint64_t *)ctx->m_u64.p, (GdSeed *)ctx->m_seed.p, (MapSeedOut *)ctx->m_seedout.p);
 		else if (!seed_classes.empty()) { // one read per wavefront, one launch per LDS capacity class
 			if ((rc = gd_grow(ctx, ctx->m_seedids, sizeof(int32_t) * (size_t)n))) return rc;
