@@ -369,6 +369,10 @@ def main():
     pkg = _load_pkg()
     pkg_cpus = pkg.effective_cpus()
     cores = max(1, pkg_cpus // max(1, local_world))  # CPUs this container may use (cgroup quota, affinity), shared by the ranks of the node
+    if world > 1 and cores < 6:
+        # several ranks on few CPUs (8 ranks on a 16-CPU quota: 2 each): every rank has two lane threads waiting for the GPU most of the time;
+        # let them sleep on a blocking event instead of spinning in hipStreamSynchronize (read when the context is created)
+        os.environ.setdefault("GDIET_SYNC", "block")
     ctx = pkg.Context(local)
 
     # the same reference on every rank (replicated index): synthesised once per node
@@ -593,7 +597,7 @@ def main():
                                                 % (1e3 * float(np.percentile(rec["latency"], 10)), 1e3 * float(np.percentile(rec["latency"], 90))),
                        "batches_in_flight": args.inflight, "self_check": check, "with_upload": with_upload,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world, "host_threads": host_threads,
-                       "cpus_usable_on_node": pkg_cpus, "pipeline_lanes": args.lanes},
+                       "cpus_usable_on_node": pkg_cpus, "pipeline_lanes": args.lanes, "gpu_waits": os.environ.get("GDIET_SYNC", "spin")},
             "roofline": dict({"bound": "hbm", "kernel": "ksw_extd2_wave_kernel<64, 0, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes_per_launch": float(alg.mean()), "dp_cells_per_launch": cells_launch,
