@@ -106,4 +106,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        # (a failed run -- e.g. a batch too large for the device -- leaves the context's worker threads alive: print the error and leave
+        # without running the interpreter's and the library's exit handlers beside them)
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
