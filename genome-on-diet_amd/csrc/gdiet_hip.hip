@@ -21,6 +21,7 @@
 #include "ksw_generic.hip.h"
 #include "ksw_backtrack.hip.h"
 #include "ksw_wave.hip.h"
+#include "ksw_pipe.hip.h"
 #include "ksw_extz2_exact.hip.h"
 #include "ksw_exts2.hip.h"
 
@@ -38,6 +39,7 @@ struct gdiet_ctx {
 	int last_mask = 0;
 	DevBuf arena;               // backtrace matrices
 	DevBuf tasks, ids, status;  // per-batch descriptors
+	DevBuf pipes;               // PipeWave records of the batch (ksw_pipe.hip.h)
 	DevBuf qseq, tseq, score, ncig, cigar; // host-API staging
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	// head / tail split of a big DP launch (see gdiet_hip_ksw_extd2_batch_dev)
@@ -54,6 +56,7 @@ struct gdiet_ctx {
 	int fuse_bt = 1;                   // GDIET_FUSE_BT=0: the 64-lane kernel leaves the backtrack to the separate kernel
 	bool single_affine = false;        // set for the duration of a gdiet_hip_ksw_extz2_batch call: single-affine kernel variants
 	std::vector<int32_t> h_ids;
+	std::vector<PipeWave> h_pipes;
 	// per-read mapping path (map_pipeline.hip.h)
 	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack, m_post, m_seedids;
 	DevBuf m_srbox, m_srtab, m_srscan, m_srcand; // device-side box stage of the ShortReads variant (map_pipeline.hip.h)
@@ -261,7 +264,7 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar,
 	                  &ctx->m_sc, &ctx->m_mv, &ctx->m_u64, &ctx->m_seed, &ctx->m_seedout, &ctx->m_voteout, &ctx->m_hitoff, &ctx->m_hits,
-	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post, &ctx->m_seedids};
+	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post, &ctx->m_seedids, &ctx->pipes};
 	for (DevBuf *b : bufs)
 		if (b->p) (void)hipFree(b->p);
 	if (ctx->h_pin.p) (void)hipHostFree(ctx->h_pin.p);
@@ -595,11 +598,43 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	// the short-alignment kernels run 4 / 6 / 8 alignments of identical (qlen, tlen, w) per wavefront (groups of 16 / 10 / 8 lanes):
 	// cut the sorted list into such groups, one list per group width (-1 pads an incomplete group)
 	std::vector<int32_t> groups[3]; // [0]: 16 lanes, [1]: 10, [2]: 8
+	// Full matrices (a short-read batch: w >= both lengths) of one geometry, enough of them to keep every group of a wavefront busy for a
+	// few alignments, run as skewed pipelines instead (ksw_pipe.hip.h): a wavefront takes np alignments per group, sized so that the
+	// run fills the GPU's wavefront slots once.  GDIET_SR_PIPE=0 keeps the grouped kernels; GDIET_PIPE_NP forces np.
+	static const bool use_pipe = !(getenv("GDIET_SR_PIPE") && atoi(getenv("GDIET_SR_PIPE")) == 0);
+	static const int pipe_np_forced = getenv("GDIET_PIPE_NP") ? atoi(getenv("GDIET_PIPE_NP")) : 0;
+	std::vector<int32_t> pipe_ids;
+	ctx->h_pipes.clear();
 	{
 		const std::vector<int32_t> &v = ids[GD_KIND_WAVE16];
 		size_t i = 0;
 		while (i < v.size()) {
 			const KswTask &A = h_tasks[v[i]];
+			if (use_pipe && gd_pipe_geometry_ok(A.qlen, A.tlen, A.w)) {
+				size_t j = i + 1;
+				while (j < v.size() && h_tasks[v[j]].qlen == A.qlen && h_tasks[v[j]].tlen == A.tlen && h_tasks[v[j]].row_bytes == A.row_bytes &&
+				       gd_pipe_geometry_ok(A.qlen, A.tlen, h_tasks[v[j]].w)) ++j;
+				const PipeGeo geo = gd_pipe_geo(A.qlen, A.tlen);
+				const size_t m = j - i;
+				if (m >= (size_t)(2 * geo.NG)) {
+					const size_t slots = (size_t)(ctx->wave_slots / 5 * 4); // (four wavefronts of this kernel per SIMD)
+					size_t np = pipe_np_forced > 0 ? (size_t)pipe_np_forced : std::max<size_t>(8, (m + geo.NG * slots - 1) / (geo.NG * slots));
+					np = std::min(np, (m + geo.NG - 1) / geo.NG);
+					const size_t n_waves = (m + geo.NG * np - 1) / (geo.NG * np);
+					size_t at = i;
+					for (size_t wv = 0; wv < n_waves; ++wv) { // the run in equal shares (the last wavefronts one alignment per group less)
+						const size_t share = (j - at + (n_waves - wv) - 1) / (n_waves - wv), np_w = (share + geo.NG - 1) / geo.NG;
+						PipeWave W;
+						memset(&W, 0, sizeof(W));
+						W.id_off = (int32_t)pipe_ids.size(), W.qlen = A.qlen, W.tlen = A.tlen, W.np = (int32_t)np_w, W.row_bytes = A.row_bytes;
+						for (size_t k = 0; k < np_w * geo.NG; ++k) pipe_ids.push_back(k < share ? v[at + k] : -1);
+						at += share;
+						ctx->h_pipes.push_back(W);
+					}
+					i = j;
+					continue;
+				}
+			}
 			const int gl = A.row_bytes >> 4, per = 64 / gl, which = gl == 16 ? 0 : gl == 10 ? 1 : 2;
 			size_t j = i + 1;
 			while (j < v.size() && j < i + per) {
@@ -617,6 +652,9 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		id_off[k] = ctx->h_ids.size();
 		if (k == GD_KIND_WAVE16) {
 			for (int g = 0; g < 3; ++g) group_off[g] = ctx->h_ids.size(), ctx->h_ids.insert(ctx->h_ids.end(), groups[g].begin(), groups[g].end());
+			for (PipeWave &W : ctx->h_pipes) W.id_off += (int32_t)ctx->h_ids.size(); // (relative to the batch's whole id list from here on)
+			ctx->h_ids.insert(ctx->h_ids.end(), pipe_ids.begin(), pipe_ids.end());
+			if (!ctx->h_pipes.empty()) ctx->last_mask |= 16;
 		} else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
 	}
 	ctx->last_cells = cells_sum, ctx->last_alg_bytes = alg_sum;
@@ -658,6 +696,10 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	if ((rc = gd_grow(ctx, ctx->status, sizeof(int32_t) * n))) return rc;
 	GD_HIP(hipMemcpyAsync(ctx->tasks.p, h_tasks, sizeof(KswTask) * n, hipMemcpyHostToDevice, stream));
 	GD_HIP(hipMemcpyAsync(ctx->ids.p, ctx->h_ids.data(), sizeof(int32_t) * ctx->h_ids.size(), hipMemcpyHostToDevice, stream));
+	if (!ctx->h_pipes.empty()) {
+		if ((rc = gd_grow(ctx, ctx->pipes, sizeof(PipeWave) * ctx->h_pipes.size()))) return rc;
+		GD_HIP(hipMemcpyAsync(ctx->pipes.p, ctx->h_pipes.data(), sizeof(PipeWave) * ctx->h_pipes.size(), hipMemcpyHostToDevice, stream));
+	}
 
 	const KswTask *d_tasks = (const KswTask *)ctx->tasks.p;
 	const int32_t *d_ids = (const int32_t *)ctx->ids.p;
@@ -709,6 +751,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		gd_launch_wave_groups<16>(d_tasks, d_ids + group_off[0], (int)(groups[0].size() / 4), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
 		gd_launch_wave_groups<10>(d_tasks, d_ids + group_off[1], (int)(groups[1].size() / 6), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
 		gd_launch_wave_groups<8>(d_tasks, d_ids + group_off[2], (int)(groups[2].size() / 8), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
+		gd_launch_pipe(d_tasks, d_ids, (const PipeWave *)ctx->pipes.p, (int)ctx->h_pipes.size(), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
 	}
 	if (!ids[GD_KIND_WAVE128].empty()) {
 		// few wide-band alignments (the arena bounds how many 50 kbp ONT alignments fit): two wavefronts share one, halving the

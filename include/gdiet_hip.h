@@ -54,7 +54,8 @@ void gdiet_hip_destroy(gdiet_ctx *ctx);
 const char *gdiet_hip_strerror(const gdiet_ctx *ctx);       /* text of the last failure on this context */
 int gdiet_hip_device_name(const gdiet_ctx *ctx, char *buf, size_t len);
 /* which kernel variants handled the last batch: bit0 = register-resident 64-lane wave kernel, bit1 = generic LDS kernel,
- * bit2 = register-resident 16-lane kernel (four short alignments per wavefront), bit3 = two-blocks-per-lane kernel (wide bands) */
+ * bit2 = register-resident short-alignment kernels (several alignments per wavefront), bit3 = two-blocks-per-lane kernel (wide bands),
+ * bit4 = some of bit2's alignments (full matrices of one geometry: a short-read batch) ran as skewed pipelines (ksw_pipe.hip.h) */
 int gdiet_hip_last_kernel_mask(const gdiet_ctx *ctx);
 
 /* ---- B3: batched banded dual-affine global alignment -------------------------------------------------------

@@ -1,0 +1,274 @@
+// Host lock-step emulator of ksw_extd2_pipe_kernel (genome-on-diet_amd/csrc/ksw_pipe.hip.h): short alignments of one geometry as a
+// skewed pipeline, a lane moving on to the group's next alignment as soon as its block has left the matrix (test infrastructure).
+// It drives the per-lane code the GPU kernel compiles (ksw_wave_core.h, ksw_pipe_core.h) with 64 emulated lanes and an emulated LDS --
+// statement by statement the device's loop, including what a lane receives from a neighbour that works on ANOTHER alignment and the
+// reuse of the two LDS buffers -- and compares score and CIGAR of every alignment with the CPU oracle (oracle/gdo_ksw2.c).
+//
+//   g++ -O2 -I genome-on-diet_amd/csrc -I oracle tests/emul/pipe_emul.cpp oracle/gdo_ksw2.c -o pipe_emul
+//   ./pipe_emul <seed> <n_pipes> [single]
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <random>
+#define __host__
+#define __device__
+#include "ksw_pipe_core.h"
+#include "gdo_ksw2.h"
+
+struct Pair { std::vector<uint8_t> q, t; int live; };
+struct EmuOut { int score = GD_NEG_INF, done = 0; std::vector<uint8_t> bt, written; };
+
+static bool g_single = false;
+
+// one wavefront: NG groups x np alignments (pairs[n * NG + g]; live == 0: the pre-filter answered it, never touched), geometry qlen x tlen
+static void emulate_pipe(const std::vector<Pair> &pairs, int np, int qlen, int tlen, int row_bytes, const KswConst &C, std::vector<EmuOut> &out)
+{
+	WaveK K;
+	if (!gdw_make_consts(C, K)) { fprintf(stderr, "consts rejected\n"); exit(2); }
+	const PipeGeo Gm = gd_pipe_geo(qlen, tlen);
+	const int G = Gm.G, NG = Gm.NG, P = Gm.P;
+	std::vector<uint8_t> lds(2 * GDP_BUF_BYTES, 0xCD);
+	if (2 * Gm.BS > (int)lds.size()) { fprintf(stderr, "LDS layout too large\n"); exit(2); }
+	int grp[64], sub[64], spare[64], nvalid[64];
+	for (int l = 0; l < 64; ++l) {
+		grp[l] = l / G, sub[l] = l % G, spare[l] = grp[l] >= NG;
+		if (spare[l]) grp[l] = 0;
+		nvalid[l] = spare[l] ? 0 : gdp_valid_rows(Gm, sub[l]);
+	}
+	out.assign(pairs.size(), EmuOut());
+	for (size_t i = 0; i < pairs.size(); ++i) out[i].bt.assign((size_t)(Gm.rend + 1) * row_bytes, 0xEE), out[i].written.assign((size_t)(Gm.rend + 1) * row_bytes, 0);
+	auto fetch = [&](const int nn) {
+		for (int l = 0; l < 64; ++l) {
+			if (spare[l]) continue;
+			const int id = nn < np ? nn * NG + grp[l] : -1;
+			const Pair *pr = id >= 0 ? &pairs[id] : nullptr;
+			const int tid_ = pr && !pr->q.empty() ? id : -1; // (an empty pair: the -1 padding of the id table)
+			const int live_ = tid_ >= 0 && pr->live;
+			uint8_t tw[16] = {0}, qw[16] = {0}, qx[16] = {0};
+			if (live_)
+				for (int b = 0; b < 16; ++b) {
+					const int t = 16 * sub[l] + b, t2 = 16 * (sub[l] + G) + b;
+					if (t < tlen) tw[b] = pr->t[t];
+					if (t < qlen) qw[b] = pr->q[t];
+					if (sub[l] < 2 && t2 < qlen) qx[b] = pr->q[t2];
+				}
+			uint8_t *B = lds.data() + (nn & 1) * Gm.BS;
+			memcpy(B + Gm.TOFF + grp[l] * Gm.TS + 16 * sub[l], tw, 16);
+			memcpy(B + grp[l] * Gm.QS + 16 * sub[l], qw, 16);
+			if (sub[l] < 2) memcpy(B + grp[l] * Gm.QS + 16 * (sub[l] + G), qx, 16);
+			if (sub[l] == 0) {
+				const int32_t d[4] = {0, 0, tid_, live_};
+				memcpy(B + Gm.DOFF + grp[l] * 16, d, 16);
+			}
+		}
+	};
+	std::vector<WaveLane> L(64);
+	int left[64], Rf[64], tid[64];
+	uint32_t qaddr[64];
+	long prow[64]; // row index the lane's next store goes to (the device keeps a pointer)
+	for (int l = 0; l < 64; ++l) {
+		const u32 z[4] = {0, 0, 0, 0};
+		gdp_start(L[l], K, z, sub[l]);
+		// (what the registers of a lane hold before its first alignment must not matter)
+		for (int k = 0; k < 8; ++k) L[l].U[k] = 0xDEAD0000u + l * 77 + k, L[l].V[k] = 0x1234ABCDu * (l + 1), L[l].X[k] = 0xBEEF0000u ^ (l << 8), L[l].X2[k] = 0x7FFF8000u;
+		left[l] = 0, Rf[l] = 0, tid[l] = -1, qaddr[l] = 0, prow[l] = 0;
+	}
+	bool any_tn = false;
+	u32 pX[64] = {0}, pV[64] = {0}, pX2[64] = {0}; // row r - 1 values of the lane below, taken at the end of a step (before any lane changes alignment)
+	fetch(0);
+	for (int n = 0; n <= np; ++n) {
+		for (int rA = 0; rA < P;) {
+			const int jsw = rA >> 4;
+			if (jsw < G) {
+				for (int l = 0; l < 64; ++l) {
+					if (sub[l] != jsw) continue;
+					if (left[l] <= 0 && tid[l] >= 0 && sub[l] == Gm.mlast) {
+						if (Rf[l] % 8) { fprintf(stderr, "tracker not a multiple of 8\n"); exit(2); }
+						out[tid[l]].score = Rf[l] / 8, out[tid[l]].done = 1;
+					}
+					const uint8_t *B = lds.data() + (n & 1) * Gm.BS;
+					int32_t d[4];
+					u32 tb[4];
+					memcpy(d, B + Gm.DOFF + grp[l] * 16, 16);
+					memcpy(tb, B + Gm.TOFF + grp[l] * Gm.TS + 16 * sub[l], 16);
+					gdp_start(L[l], K, tb, sub[l]);
+					const bool live = n < np && d[3] != 0 && !spare[l];
+					tid[l] = live ? d[2] : -1;
+					left[l] = live ? nvalid[l] : 0;
+					Rf[l] = 0;
+					qaddr[l] = (u32)((n & 1) * Gm.BS + grp[l] * Gm.QS);
+					prow[l] = 16 * sub[l];
+				}
+				any_tn = false;
+				for (int l = 0; l < 64; ++l) any_tn |= L[l].tn != 0;
+				if (jsw == G - 1) {
+					if (n == np) goto done;
+					fetch(n + 1);
+				}
+			}
+			const int rows_here = P - rA < 16 ? P - rA : 16, r_stop = rA + rows_here;
+			for (bool first = true; rA < r_stop; ++rA, first = false) {
+				u32 qb[64];
+				for (int l = 0; l < 64; ++l) {
+					if (qaddr[l] >= lds.size()) { fprintf(stderr, "LDS read out of range\n"); exit(2); }
+					qb[l] = lds[qaddr[l]];
+					++qaddr[l];
+				}
+				for (int l = 0; l < 64; ++l) {
+					WaveRow W;
+					W.r = rA, W.st0 = 0, W.en0 = 0, W.st_ = 0, W.en_ = 0, W.up = 0;
+					W.use_array = 0, W.set_tr = 1, W.ukey = gdw_edge_key(K, rA), W.v1key = W.ukey;
+					W.m_first_valid = 1, W.m_first = sub[l] == 0 ? ~0u : 0u;
+					if (jsw < G) gdw_reset_tr(L[l], K, W);
+					gdp_query_scores(L[l], K, qb[l], any_tn);
+					u32 o[4];
+					if (g_single) gdw_compute<false>(L[l], K, W, pX[l], pV[l], pX2[l], o);
+					else gdw_compute<true>(L[l], K, W, pX[l], pV[l], pX2[l], o);
+					if (left[l] > 0) {
+						if (tid[l] < 0 || prow[l] > Gm.rend) { fprintf(stderr, "store outside an alignment\n"); exit(2); }
+						memcpy(&out[tid[l]].bt[(size_t)prow[l] * row_bytes + 16 * sub[l]], o, 16);
+						memset(&out[tid[l]].written[(size_t)prow[l] * row_bytes + 16 * sub[l]], 1, 16);
+					}
+					++prow[l];
+					L[l].R += gdw_lo(L[l].V[0]) - K.B1;
+				}
+				for (int l = 0; l < 64; ++l) {
+					const int p = (l + 63) & 63;
+					pX[l] = L[p].X[7], pV[l] = L[p].V[7], pX2[l] = L[p].X2[7];
+				}
+				if (first && jsw >= 1 && jsw < G) {
+					int h[64];
+					for (int l = 0; l < 64; ++l) h[l] = gdw_track_handoff(L[(l + 63) & 63]);
+					for (int l = 0; l < 64; ++l)
+						if (sub[l] == jsw) L[l].R = h[l] + gdw_lo(L[l].U[0]);
+				}
+				for (int l = 0; l < 64; ++l) {
+					if (sub[l] == Gm.mlast) {
+						if (left[l] == qlen) Rf[l] = gdw_track_to_slot(L[l], Gm.sl);
+						else if (left[l] > 0 && left[l] < qlen) Rf[l] += gdw_cell(L[l].V, Gm.sl) - K.B1;
+					}
+					--left[l];
+				}
+			}
+		}
+	}
+done:;
+}
+
+// the walk over the emulated backtrace (converted to the reference's layout), by the oracle's backtrack
+static std::vector<uint32_t> walk(const EmuOut &e, int qlen, int tlen, int w, int row_bytes)
+{
+	if (w < 0) w = tlen > qlen ? tlen : qlen; // (SR/ksw2_extd2_sse.c:90)
+	const int rend = qlen + tlen - 2, ncol = gd_ncol16(qlen, tlen, w);
+	std::vector<uint8_t> p((size_t)(rend + 1) * ncol * 16 + 16, 0);
+	std::vector<int> off(2 * (rend + 1));
+	for (int r = 0; r <= rend; ++r) {
+		int st0, en0;
+		gd_band(r, qlen, tlen, w, st0, en0);
+		if (st0 != (r - qlen + 1 > 0 ? r - qlen + 1 : 0) || en0 != (r < tlen - 1 ? r : tlen - 1)) { fprintf(stderr, "admitted geometry is not a full matrix\n"); exit(2); }
+		const int st = st0 & ~15, en = en0 | 15;
+		off[r] = st, off[rend + 1 + r] = en;
+		for (int i = st0; i <= en0; ++i) { // (the cells of the matrix; whatever else the reference's rows hold is never read)
+			const int c = i & 15, g = (c & 7) >> 1, h = (c & 1) | ((c >> 3) << 1);
+			const size_t at = (size_t)r * row_bytes + (i >> 4) * 16 + 4 * g + h;
+			if (!e.written[at]) { fprintf(stderr, "cell (%d, %d) of the matrix was never stored\n", r, i); exit(2); }
+			const uint8_t b = e.bt[at], nb = (uint8_t)~b;
+			p[(size_t)r * ncol * 16 + (i - st)] = (uint8_t)((4 - (b & 7)) | ((nb >> 4) & 0x08) | ((nb >> 2) & 0x10) | (nb & 0x20) | ((nb << 2) & 0x40));
+		}
+	}
+	int m_cigar = 0, n_cigar = 0;
+	uint32_t *cigar = 0;
+	gdo_backtrack(0, 0, p.data(), off.data(), off.data() + rend + 1, ncol * 16, tlen - 1, qlen - 1, &m_cigar, &n_cigar, &cigar);
+	std::vector<uint32_t> v(cigar, cigar + n_cigar);
+	free(cigar);
+	return v;
+}
+
+// a query of exactly qlen bases related to t (|qlen - tlen| <= 15): substitutions, a few indels, then trimmed / padded at random places
+static void make_query(std::mt19937 &g, const std::vector<uint8_t> &t, int qlen, double sub, double indel, bool with_n, std::vector<uint8_t> &q)
+{
+	std::uniform_real_distribution<double> U(0, 1);
+	q.clear();
+	for (uint8_t c : t) {
+		const double r = U(g);
+		if (r < indel) continue;
+		if (r < 2 * indel) q.push_back(g() & 3);
+		if (U(g) < sub) c = (c + 1 + g() % 3) & 3;
+		if (with_n && U(g) < 0.02) c = 4;
+		q.push_back(c);
+	}
+	while ((int)q.size() > qlen) q.erase(q.begin() + g() % q.size());
+	while ((int)q.size() < qlen) q.insert(q.begin() + g() % (q.size() + 1), (uint8_t)(g() & 3));
+}
+
+int main(int argc, char **argv)
+{
+	const unsigned seed = argc > 1 ? atoi(argv[1]) : 1;
+	const int n_pipes = argc > 2 ? atoi(argv[2]) : 20;
+	g_single = argc > 3 && !strcmp(argv[3], "single");
+	std::mt19937 g(seed);
+	const int presets[3][6] = {{2, 8, 12, 2, 24, 1}, {1, 4, 6, 2, 26, 1}, {2, 4, 4, 2, 24, 1}};
+	int n_run = 0, n_bad = 0, n_geo_refused = 0;
+	for (int it = 0; it < n_pipes; ++it) {
+		const int *Pz = presets[it % 3];
+		int tlen = it % 3 == 0 ? 150 : 17 + g() % 144, qlen = it % 3 == 0 ? 150 : tlen + (int)(g() % 31) - 15;
+		if (qlen < 17) qlen = 17;
+		const int wmax = tlen > qlen ? tlen : qlen;
+		const int w = it % 4 == 1 ? -1 : wmax + g() % 60;
+		if (!gd_pipe_geometry_ok(qlen, tlen, w)) { ++n_geo_refused; continue; }
+		const PipeGeo Gm = gd_pipe_geo(qlen, tlen);
+		if (16 * (Gm.G - 1) >= Gm.P || Gm.QS < Gm.P + 1 || Gm.G < 2 || Gm.G > 10) { fprintf(stderr, "geometry invariants\n"); return 2; }
+		const int np = 1 + g() % 5, row_bytes = 16 * (tlen <= 128 ? 8 : 10); // (the planner's row stride: that of the 8- / 10-lane groups)
+		KswConst C;
+		C.q = Pz[2], C.e = Pz[3], C.q2 = g_single ? Pz[2] : Pz[4], C.e2 = g_single ? Pz[3] : Pz[5];
+		if (C.q2 + C.e2 < C.q + C.e) std::swap(C.q, C.q2), std::swap(C.e, C.e2);
+		C.sc_mch = Pz[0], C.sc_mis = -Pz[1], C.sc_N = -C.e2;
+		C.long_thres = C.e != C.e2 ? (C.q2 - C.q) / (C.e - C.e2) - 1 : 0;
+		if (C.q2 + C.e2 + C.long_thres * C.e2 > C.q + C.e + C.long_thres * C.e) ++C.long_thres;
+		C.long_diff = C.long_thres * (C.e - C.e2) - (C.q2 - C.q) - C.e2;
+		std::vector<Pair> pairs((size_t)np * Gm.NG);
+		for (size_t i = 0; i < pairs.size(); ++i) {
+			Pair &p = pairs[i];
+			const unsigned kind = g() % 16;
+			if (kind == 0) { p.live = 0; continue; } // padding of the id table (-1)
+			p.t.resize(tlen);
+			for (auto &c : p.t) c = g() & 3;
+			const bool with_n = g() % 7 == 0;
+			if (with_n) for (auto &c : p.t) if (g() % 50 == 0) c = 4;
+			const double sub = kind < 4 ? 0.01 : kind < 10 ? 0.05 : 0.15, indel = kind < 4 ? 0.003 : kind < 12 ? 0.02 : 0.06;
+			make_query(g, p.t, qlen, sub, indel, with_n, p.q);
+			if (g() % 4 == 1 && !g_single) for (auto &c : p.q) if (c == 4 || g() % 100 == 0) c = 7; // N of a reverse-complemented read (LR/map.c:1634)
+			p.live = kind != 1; // kind 1: answered by the exact-match pre-filter -- the kernel must leave it alone
+		}
+		std::vector<EmuOut> out;
+		emulate_pipe(pairs, np, qlen, tlen, row_bytes, C, out);
+		int8_t mat[25];
+		for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? Pz[0] : -Pz[1]);
+		for (size_t i = 0; i < pairs.size(); ++i) {
+			const Pair &p = pairs[i];
+			if (p.q.empty() || !p.live) {
+				if (out[i].done) { fprintf(stderr, "a dead alignment was written\n"); ++n_bad; }
+				for (uint8_t b : out[i].written) if (b) { fprintf(stderr, "a dead alignment's backtrace was written\n"); ++n_bad; break; }
+				continue;
+			}
+			gdo_extz_t ez;
+			memset(&ez, 0, sizeof(ez));
+			if (g_single) gdo_ksw_extz2(qlen, p.q.data(), tlen, p.t.data(), 5, mat, Pz[2], Pz[3], w, -1, 0, GDO_EZ_APPROX_MAX, &ez);
+			else gdo_ksw_extd2(qlen, p.q.data(), tlen, p.t.data(), 5, mat, Pz[2], Pz[3], Pz[4], Pz[5], w, -1, 0, GDO_EZ_APPROX_MAX | GDO_EZ_AVX512_SC, &ez);
+			++n_run;
+			bool ok = out[i].done && out[i].score == ez.score;
+			if (ok) {
+				const std::vector<uint32_t> cg = walk(out[i], qlen, tlen, w, row_bytes);
+				ok = (int)cg.size() == ez.n_cigar && (ez.n_cigar == 0 || !memcmp(cg.data(), ez.cigar, 4 * ez.n_cigar));
+			}
+			if (!ok) {
+				++n_bad;
+				if (n_bad <= 10) fprintf(stderr, "MISMATCH pipe=%d pair=%zu qlen=%d tlen=%d w=%d np=%d done=%d score emu=%d oracle=%d\n", it, i, qlen, tlen, w, np, out[i].done, out[i].score, ez.score);
+			}
+			free(ez.cigar);
+		}
+	}
+	printf("pipe_emul pipes=%d alignments_run=%d refused=%d mismatches=%d\n", n_pipes, n_run, n_geo_refused, n_bad);
+	return n_bad ? 1 : (n_run ? 0 : 3);
+}

@@ -52,7 +52,7 @@ def test_extz2_config2_shape_against_oracle(gpu_ctx, pkg, oracle):
     qs[0] = T[0].copy()
     score = pkg.KswScore.from_preset("sr")
     sc, cg = gpu_ctx.ksw_extz2_batch(qs, ts, 150, score)
-    assert gpu_ctx.last_kernel_mask() == 4  # everything on the 16-lane kernel
+    assert gpu_ctx.last_kernel_mask() in (4, 20)  # everything on the short-alignment kernels (bit 4: as skewed pipelines)
     a, b, q_, e, _, _ = gdo.PRESETS["sr"]
     mat = gdo.score_matrix(a, b)
     assert sc[0] == 150 * a and list(cg[0]) == [150 << 4]

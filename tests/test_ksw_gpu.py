@@ -140,6 +140,48 @@ def test_short_read_quartets_match_oracle(gpu_ctx, pkg, oracle):
     assert n_exact >= 30
 
 
+def test_short_read_pipelines_match_oracle(gpu_ctx, pkg, oracle):
+    """full matrices of one geometry as skewed pipelines (ksw_extd2_pipe_kernel: a lane starts the group's next alignment as soon as its
+    block has left the matrix): 2 to 10 lanes per alignment, qlen on both sides of tlen, runs that end inside a wavefront's share,
+    exact-match rows (answered by the pre-filter: their slot of the pipe stays silent), Ns, and heavy error rates whose best paths
+    use the whole matrix -- against the oracle; the other geometries of the batch stay on the grouped kernels"""
+    gdo, lib = oracle
+    rng = np.random.default_rng(515)
+    qs, ts, ws = [], [], []
+    geos = [(150, 150, 150, 333), (150, 150, 171, 40), (17, 17, 20, 70), (36, 49, 49, 77), (128, 114, 128, 90), (100, 100, 150, 64), (160, 160, 160, 29),
+            (155, 145, 200, 50), (59, 66, 72, 130), (33, 48, 48, 25), (150, 151, 151, 13)]
+    for ql, tl, w, cnt in geos:
+        for i in range(cnt):
+            err = (0.01, 0.002) if i % 3 == 0 else (0.05, 0.02) if i % 3 == 1 else (0.15, 0.06)
+            q, t = gdo.make_pair(rng, max(ql, tl) + 40, err[0], err[1], err[1], n_frac=0.02 if i % 9 == 4 else 0.0)
+            q, t = q[:ql], t[:tl]
+            assert len(q) == ql and len(t) == tl
+            if i % 13 == 5 and ql == tl:
+                q = t.copy()
+            qs.append(np.ascontiguousarray(q)), ts.append(np.ascontiguousarray(t)), ws.append(w)
+    for i in range(60):  # narrow bands and lone geometries: not for the pipelines
+        n = int(rng.integers(40, 200))
+        q, t = gdo.make_pair(rng, n, 0.03, 0.01, 0.01)
+        qs.append(q), ts.append(t), ws.append(int(rng.integers(20, 60)))
+    order = rng.permutation(len(qs))
+    qs, ts, ws = [qs[i] for i in order], [ts[i] for i in order], [ws[i] for i in order]
+    ex = np.array([len(q) * 2 if len(q) == len(t) else pkg.hip_abi.NEG_INF for q, t in zip(qs, ts)], np.int32)
+    sc, cg = gpu_ctx.ksw_extd2_batch(qs, ts, ws, pkg.KswScore.from_preset("sr"), exact_score=ex)
+    assert gpu_ctx.last_kernel_mask() & 16
+    a, b, q_, e, q2, e2 = gdo.PRESETS["sr"]
+    mat = gdo.score_matrix(a, b)
+    n_exact = 0
+    for i in range(len(qs)):
+        if len(qs[i]) == len(ts[i]) and np.array_equal(qs[i], ts[i]):
+            assert sc[i] == ex[i] and list(cg[i]) == [len(qs[i]) << 4]
+            n_exact += 1
+            continue
+        o = gdo.oracle_extd2(lib, qs[i], ts[i], mat, q_, e, q2, e2, ws[i])
+        assert sc[i] == o["score"], (i, len(qs[i]), len(ts[i]), ws[i], sc[i], o["score"])
+        assert np.array_equal(cg[i], o["cigar"]), (i, len(qs[i]), len(ts[i]), ws[i])
+    assert n_exact >= 20
+
+
 def test_short_read_group_widths_match_oracle(gpu_ctx, pkg, oracle):
     """the short-alignment kernels pack 8 / 6 / 4 alignments of one geometry into a wavefront (groups of 8 / 10 / 16 lanes for
     targets of <= 128 / <= 160 / more bases): targets on both sides of each limit, full and padded groups, narrow and full bands,

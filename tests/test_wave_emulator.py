@@ -69,3 +69,22 @@ def test_checkpointed_96_block_ring_matches_oracle(emul, seed, n, rows):
     out = emul[("ring96", seed, n, rows)].result()
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches=0" in out.stdout
+
+
+@pytest.fixture(scope="module")
+def pipe_emul(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("emul") / "pipe_emul")
+    subprocess.check_call(["g++", "-O2", "-w", "-I", os.path.join(ROOT, "genome-on-diet_amd", "csrc"), "-I", os.path.join(ROOT, "oracle"),
+                           os.path.join(ROOT, "tests", "emul", "pipe_emul.cpp"), "-x", "c", os.path.join(ROOT, "oracle", "gdo_ksw2.c"), "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("seed,n,single", [(1, 120, False), (2, 120, False), (3, 80, True)])
+def test_skewed_pipeline_matches_oracle(pipe_emul, seed, n, single):
+    """ksw_extd2_pipe_kernel (full-matrix short alignments; a lane starts the group's next alignment as soon as its block has left
+    the matrix): the device's loop statement by statement on 64 emulated lanes and an emulated LDS -- random geometries of 2..10 blocks,
+    1..5 alignments per group, dead slots, Ns, error rates up to 15 % + 12 % indels, what a lane receives from a neighbour on another
+    alignment -- score and CIGAR of every alignment against the oracle; every cell of a matrix must have been stored"""
+    out = subprocess.run([pipe_emul, str(seed), str(n)] + (["single"] if single else []), capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout
