@@ -16,17 +16,23 @@
 // one wavefront's work: np alignments per group, ids at task_ids[id_off + n * NG + g] (-1: none), all of geometry qlen x tlen
 struct PipeWave { int32_t id_off, qlen, tlen, np, row_bytes, pad[3]; };
 
+// Four wavefronts per workgroup, each with a pipe and an LDS region of its own and no barrier between them: the dispatcher then puts one
+// on each SIMD of a CU (single-wavefront workgroups were spread unevenly: 2 743 of 3 922 wavefronts resident on average, the kernel as
+// long as the fullest SIMD needs).
+#define GDP_BLOCK_WAVES 4
 template <bool DUAL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ksw_extd2_pipe_kernel(const KswTask *__restrict__ tasks, const int32_t *__restrict__ task_ids,
+__global__ __launch_bounds__(64 * GDP_BLOCK_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void ksw_extd2_pipe_kernel(const KswTask *__restrict__ tasks, const int32_t *__restrict__ task_ids,
                                                            const PipeWave *__restrict__ pipes, int n_pipes,
                                                            const uint8_t *__restrict__ qseq, const uint8_t *__restrict__ tseq,
                                                            uint8_t *__restrict__ bt, int32_t *__restrict__ status,
                                                            int32_t *__restrict__ score_out, WaveK K)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t lds[2 * GDP_BUF_BYTES];
+	__shared__ __attribute__((aligned(16))) uint8_t lds_all[GDP_BLOCK_WAVES][2 * GDP_BUF_BYTES];
 	const int lane = threadIdx.x & 63;
-	const int pw = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int pw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * GDP_BLOCK_WAVES + wv);
 	if (pw >= n_pipes) return;
+	uint8_t *const lds = lds_all[wv];
 	const int id_off = __builtin_amdgcn_readfirstlane(pipes[pw].id_off), np = __builtin_amdgcn_readfirstlane(pipes[pw].np);
 	const int row_bytes = __builtin_amdgcn_readfirstlane(pipes[pw].row_bytes);
 	const PipeGeo Gm = gd_pipe_geo(__builtin_amdgcn_readfirstlane(pipes[pw].qlen), __builtin_amdgcn_readfirstlane(pipes[pw].tlen));
@@ -49,24 +55,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ks
 			live_ = status[tid_] == GD_ST_PENDING; // (else the exact-match pre-filter answered this one)
 			qo = tasks[tid_].qoff, to = tasks[tid_].toff, bo = tasks[tid_].bt_off;
 		}
-		u32 tw[4] = {0, 0, 0, 0}, qw[4] = {0, 0, 0, 0}, qx[4] = {0, 0, 0, 0};
-		if (live_) {
+		// (one 16-byte piece at a time: gathered, stored, forgotten -- the DP state of the lane stays in its registers meanwhile)
+		auto piece = [&](const uint8_t *__restrict__ src, const int first, const int len, uint8_t *dst) __attribute__((always_inline)) {
+			u32 w4[4] = {0, 0, 0, 0};
+			if (live_) {
 #pragma unroll
-			for (int b = 0; b < 16; ++b) {
-				const int t = 16 * sub + b, t2 = 16 * (sub + G) + b;
-				if (t < tlen) tw[b >> 2] |= (u32)tseq[to + t] << (8 * (b & 3));
-				if (t < qlen) qw[b >> 2] |= (u32)qseq[qo + t] << (8 * (b & 3));
-				if (sub < 2 && t2 < qlen) qx[b >> 2] |= (u32)qseq[qo + t2] << (8 * (b & 3));
+				for (int b = 0; b < 16; ++b)
+					if (first + b < len) w4[b >> 2] |= (u32)src[first + b] << (8 * (b & 3));
 			}
-		}
+			*reinterpret_cast<uint4 *>(dst) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+		};
 		if (!spare) {
 			uint8_t *B = lds + (nn & 1) * Gm.BS;
-			*reinterpret_cast<uint4 *>(B + Gm.TOFF + grp * Gm.TS + 16 * sub) = make_uint4(tw[0], tw[1], tw[2], tw[3]);
-			*reinterpret_cast<uint4 *>(B + grp * Gm.QS + 16 * sub) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
-			if (sub < 2) *reinterpret_cast<uint4 *>(B + grp * Gm.QS + 16 * (sub + G)) = make_uint4(qx[0], qx[1], qx[2], qx[3]);
+			piece(tseq + to, 16 * sub, tlen, B + Gm.TOFF + grp * Gm.TS + 16 * sub);
+			piece(qseq + qo, 16 * sub, qlen, B + grp * Gm.QS + 16 * sub);
+			if (sub < 2) piece(qseq + qo, 16 * (sub + G), qlen, B + grp * Gm.QS + 16 * (sub + G));
 			if (sub == 0) *reinterpret_cast<uint4 *>(B + Gm.DOFF + grp * 16) = make_uint4((u32)(uint64_t)bo, (u32)((uint64_t)bo >> 32), (u32)tid_, (u32)live_);
 		}
-		__syncthreads(); // (one wavefront per workgroup: orders the LDS writes before the reads of the other lanes)
+		// (the region belongs to this wavefront alone and a wavefront's LDS operations complete in order: only the compiler must not move
+		// the other lanes' reads above these writes)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	};
 
 	WaveLane L;
@@ -81,13 +91,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ks
 	// row r - 1 values of the lane below, taken at the END of a step: the lane below may start its next alignment before the step
 	// that consumes them (its last row on this alignment is the very row the cell above it still needs: ksw_pipe_core.h)
 	u32 pX = 0, pV = 0, pX2 = 0;
+	u32 qb = 0; // the query byte of the next step, read a step ahead (the LDS latency then lies behind a whole row of arithmetic)
+	// the boundary key of row rA (v1 of block 0, u of the cell t == r): it changes on four rows of a period only
+	int ekey = K.key_open;
+	const int lt = K.long_thres;
 	fetch(0);
+	// One step.  KK = 0..7: the lanes of block `jsw` (mask m_reset: their half of register KK) are in their first 16 rows and reset the
+	// cell t == r in register KK; KK = -1: the generic form of the reset (a chunk cut short by the end of the period); KK = -2: none.
+	// TRACK: the chunk in which block mlast reaches the last query row (below).
+	auto step = [&](const int rA, const int jsw, const bool first, const u32 m_reset, const bool track, auto ktag) __attribute__((always_inline)) {
+		constexpr int KK = decltype(ktag)::value;
+		if (rA == 0 || rA == 1 || rA == lt || rA == lt + 1) ekey = gdw_edge_key(K, rA);
+		WaveRow W;
+		W.r = rA, W.st0 = 0, W.en0 = 0, W.st_ = 0, W.en_ = 0, W.up = 0;
+		W.use_array = 0, W.set_tr = 1, W.ukey = ekey, W.v1key = ekey;
+		W.m_first_valid = 1, W.m_first = m_first;
+		if (KK >= 0) {
+			L.U[KK] = gdw_bfi(m_reset, gdw_pack2(ekey), L.U[KK]);
+			L.Y[KK] = gdw_bfi(m_reset, K.cy, L.Y[KK]);
+			if (DUAL) L.Y2[KK] = gdw_bfi(m_reset, K.cy2, L.Y2[KK]);
+		} else if (KK == -1) gdw_reset_tr(L, K, W);
+		gdp_query_scores(L, K, qb, any_tn);
+		qb = lds[qaddr]; // (for the next step; a lane that changes alignment first re-reads it)
+		++qaddr;
+		u32 out[4];
+		gdw_compute<DUAL>(L, K, W, pX, pV, pX2, out);
+		pX = gdw_ror1<64>(L.X[7]), pV = gdw_ror1<64>(L.V[7]), pX2 = DUAL ? gdw_ror1<64>(L.X2[7]) : 0u; // for the next step
+		if (left > 0) *reinterpret_cast<uint4 *>(p_row) = make_uint4(out[0], out[1], out[2], out[3]);
+		p_row += row_bytes;
+		L.R += gdw_lo(L.V[0]) - K.B1;
+		if (first && jsw >= 1 && jsw < G) { // block jsw enters the matrix: its tracker from the block below
+			const int h = (int)gdw_ror1<64>((u32)gdw_track_handoff(L));
+			if (sub == jsw) L.R = h + gdw_lo(L.U[0]);
+		}
+		// The score = H of the last cell.  Block mlast tracks H at its cell 0 down to the last query row (r* = 16 mlast + qlen - 1, the
+		// first row of chunk mlast - 1 of the NEXT period: r* - P = 16 (mlast - 1)); there the tracker walks along the anti-diagonal to the
+		// last target column (sl cells, all on rows of the query) and follows that column down for the sl rows that remain.
+		if (track && sub == Gm.mlast && left > 0) {
+			if (first) Rf = gdw_track_to_slot(L, Gm.sl);
+			else Rf += gdw_cell(L.V, Gm.sl) - K.B1;
+		}
+		--left;
+		__builtin_amdgcn_sched_barrier(0); // (the steps of an unrolled chunk one after the other: interleaved they do not fit the registers)
+	};
 	for (int n = 0; n <= np; ++n) { // period n: lane 0 of every group starts alignment n (n == np: the last alignments drain)
 		for (int rA = 0; rA < P;) {
 			const int jsw = rA >> 4; // rows [16 jsw, 16 jsw + 15] of the period: block jsw changes alignment on the first of them
 			if (jsw < G) {
 				if (sub == jsw) {
-					if (left <= 0 && tid >= 0 && sub == Gm.mlast) score_out[tid] = Rf >> 3, status[tid] = GD_ST_DONE; // (tid >= 0: a live alignment, all rows done)
+					if (tid >= 0 && sub == Gm.mlast) score_out[tid] = Rf >> 3, status[tid] = GD_ST_DONE; // (a live alignment, all rows done)
 					const uint8_t *B = lds + (n & 1) * Gm.BS;
 					const uint4 d = *reinterpret_cast<const uint4 *>(B + Gm.DOFF + grp * 16);
 					const uint4 t4 = *reinterpret_cast<const uint4 *>(B + Gm.TOFF + grp * Gm.TS + 16 * sub);
@@ -98,6 +150,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ks
 					left = live ? nvalid : 0;
 					Rf = 0;
 					qaddr = (u32)((n & 1) * Gm.BS + grp * Gm.QS);
+					qb = lds[qaddr];
+					++qaddr;
 					p_row = bt + (((uint64_t)d.y << 32) | d.x) + (size_t)sub * 16 + (size_t)(16 * sub) * (size_t)row_bytes;
 				}
 				any_tn = __builtin_amdgcn_ballot_w64(L.tn != 0) != 0;
@@ -106,37 +160,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ks
 					fetch(n + 1);
 				}
 			}
-			const int rows_here = P - rA < 16 ? P - rA : 16;
-			const int r_stop = rA + rows_here;
+			const bool track = jsw == Gm.mlast - 1;
+			if (jsw < G && P - rA >= 16) {
+				// sixteen rows with the cell t == r of block jsw in register 0..7, low then high half
 #pragma unroll 1
-			for (bool first = true; rA < r_stop; ++rA, first = false) {
-				// (1) the query byte this lane's first cell meets
-				const u32 qb = lds[qaddr];
-				++qaddr;
-				// (2) the cell t == r of the lanes in their first 16 rows (all of them on lane 0's alignment, at row rA), query, scores
-				WaveRow W;
-				W.r = rA, W.st0 = 0, W.en0 = 0, W.st_ = 0, W.en_ = 0, W.up = 0;
-				W.use_array = 0, W.set_tr = 1, W.ukey = gdw_edge_key(K, rA), W.v1key = W.ukey;
-				W.m_first_valid = 1, W.m_first = m_first;
-				if (jsw < G) gdw_reset_tr(L, K, W);
-				gdp_query_scores(L, K, qb, any_tn);
-				// (3) the 16 cells
-				u32 out[4];
-				gdw_compute<DUAL>(L, K, W, pX, pV, pX2, out);
-				pX = gdw_ror1<64>(L.X[7]), pV = gdw_ror1<64>(L.V[7]), pX2 = DUAL ? gdw_ror1<64>(L.X2[7]) : 0u; // for the next step
-				if (left > 0) *reinterpret_cast<uint4 *>(p_row) = make_uint4(out[0], out[1], out[2], out[3]);
-				p_row += row_bytes;
-				// (4) score trackers
-				L.R += gdw_lo(L.V[0]) - K.B1;
-				if (first && jsw >= 1 && jsw < G) {
-					const int h = (int)gdw_ror1<64>((u32)gdw_track_handoff(L));
-					if (sub == jsw) L.R = h + gdw_lo(L.U[0]);
+				for (int half = 0; half < 2; ++half) {
+					const u32 m_reset = sub == jsw ? (half ? 0xffff0000u : 0x0000ffffu) : 0u;
+					step(rA, jsw, half == 0, m_reset, track, std::integral_constant<int, 0>());
+					step(rA + 1, jsw, false, m_reset, track, std::integral_constant<int, 1>());
+					step(rA + 2, jsw, false, m_reset, track, std::integral_constant<int, 2>());
+					step(rA + 3, jsw, false, m_reset, track, std::integral_constant<int, 3>());
+					step(rA + 4, jsw, false, m_reset, track, std::integral_constant<int, 4>());
+					step(rA + 5, jsw, false, m_reset, track, std::integral_constant<int, 5>());
+					step(rA + 6, jsw, false, m_reset, track, std::integral_constant<int, 6>());
+					step(rA + 7, jsw, false, m_reset, track, std::integral_constant<int, 7>());
+					rA += 8;
 				}
-				if (sub == Gm.mlast) {
-					if (left == qlen) Rf = gdw_track_to_slot(L, Gm.sl);
-					else if (left > 0 && left < qlen) Rf += gdw_cell(L.V, Gm.sl) - K.B1;
+			} else {
+				const int r_stop = P - rA < 16 ? P : rA + 16;
+				if (jsw < G) {
+#pragma unroll 1
+					for (bool first = true; rA < r_stop; ++rA, first = false) step(rA, jsw, first, 0u, track, std::integral_constant<int, -1>());
+				} else {
+#pragma unroll 1
+					for (bool first = true; rA < r_stop; ++rA, first = false) step(rA, jsw, first, 0u, false, std::integral_constant<int, -2>());
 				}
-				--left;
 			}
 		}
 	}
@@ -148,6 +196,7 @@ static inline void gd_launch_pipe(const KswTask *tasks, const int32_t *ids, cons
 	if (n_pipes <= 0) return;
 	WaveK K;
 	gdw_make_consts(C, K);
-	if (single) hipLaunchKernelGGL((ksw_extd2_pipe_kernel<false>), dim3(n_pipes), dim3(64), 0, s, tasks, ids, pipes, n_pipes, q, t, bt, status, score, K);
-	else hipLaunchKernelGGL((ksw_extd2_pipe_kernel<true>), dim3(n_pipes), dim3(64), 0, s, tasks, ids, pipes, n_pipes, q, t, bt, status, score, K);
+	const dim3 grid((n_pipes + GDP_BLOCK_WAVES - 1) / GDP_BLOCK_WAVES), block(64 * GDP_BLOCK_WAVES);
+	if (single) hipLaunchKernelGGL((ksw_extd2_pipe_kernel<false>), grid, block, 0, s, tasks, ids, pipes, n_pipes, q, t, bt, status, score, K);
+	else hipLaunchKernelGGL((ksw_extd2_pipe_kernel<true>), grid, block, 0, s, tasks, ids, pipes, n_pipes, q, t, bt, status, score, K);
 }

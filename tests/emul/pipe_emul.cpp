@@ -76,14 +76,69 @@ static void emulate_pipe(const std::vector<Pair> &pairs, int np, int qlen, int t
 	}
 	bool any_tn = false;
 	u32 pX[64] = {0}, pV[64] = {0}, pX2[64] = {0}; // row r - 1 values of the lane below, taken at the end of a step (before any lane changes alignment)
+	u32 qb[64] = {0};                                // the query byte of the next step, read a step ahead
+	int ekey = K.key_open;
+	const int lt = K.long_thres;
 	fetch(0);
+	// one step of all 64 lanes; KK as on the device (0..7: static register of the cell t == r, -1: generic reset, -2: none)
+	auto step = [&](const int rA, const int jsw, const bool first, const int half, const bool track, const int KK) {
+		if (rA == 0 || rA == 1 || rA == lt || rA == lt + 1) ekey = gdw_edge_key(K, rA);
+		if (ekey != gdw_edge_key(K, rA)) { fprintf(stderr, "edge key bookkeeping\n"); exit(2); }
+		for (int l = 0; l < 64; ++l) {
+			WaveRow W;
+			W.r = rA, W.st0 = 0, W.en0 = 0, W.st_ = 0, W.en_ = 0, W.up = 0;
+			W.use_array = 0, W.set_tr = 1, W.ukey = ekey, W.v1key = ekey;
+			W.m_first_valid = 1, W.m_first = sub[l] == 0 ? ~0u : 0u;
+			if (KK >= 0) {
+				const u32 m_reset = sub[l] == jsw ? (half ? 0xffff0000u : 0x0000ffffu) : 0u;
+				if (KK != (rA & 7) || half != ((rA >> 3) & 1)) { fprintf(stderr, "unrolled chunk out of step\n"); exit(2); }
+				L[l].U[KK] = gdw_bfi(m_reset, gdw_pack2(ekey), L[l].U[KK]);
+				L[l].Y[KK] = gdw_bfi(m_reset, K.cy, L[l].Y[KK]);
+				if (!g_single) L[l].Y2[KK] = gdw_bfi(m_reset, K.cy2, L[l].Y2[KK]);
+			} else if (KK == -1) gdw_reset_tr(L[l], K, W);
+			gdp_query_scores(L[l], K, qb[l], any_tn);
+			if (qaddr[l] >= lds.size()) { fprintf(stderr, "LDS read out of range\n"); exit(2); }
+			qb[l] = lds[qaddr[l]];
+			++qaddr[l];
+			u32 o[4];
+			if (g_single) gdw_compute<false>(L[l], K, W, pX[l], pV[l], pX2[l], o);
+			else gdw_compute<true>(L[l], K, W, pX[l], pV[l], pX2[l], o);
+			if (left[l] > 0) {
+				if (tid[l] < 0 || prow[l] > Gm.rend) { fprintf(stderr, "store outside an alignment\n"); exit(2); }
+				memcpy(&out[tid[l]].bt[(size_t)prow[l] * row_bytes + 16 * sub[l]], o, 16);
+				memset(&out[tid[l]].written[(size_t)prow[l] * row_bytes + 16 * sub[l]], 1, 16);
+			}
+			++prow[l];
+			L[l].R += gdw_lo(L[l].V[0]) - K.B1;
+		}
+		for (int l = 0; l < 64; ++l) {
+			const int p = (l + 63) & 63;
+			pX[l] = L[p].X[7], pV[l] = L[p].V[7], pX2[l] = g_single ? 0u : L[p].X2[7];
+		}
+		if (first && jsw >= 1 && jsw < G) {
+			int h[64];
+			for (int l = 0; l < 64; ++l) h[l] = gdw_track_handoff(L[(l + 63) & 63]);
+			for (int l = 0; l < 64; ++l)
+				if (sub[l] == jsw) L[l].R = h[l] + gdw_lo(L[l].U[0]);
+		}
+		for (int l = 0; l < 64; ++l) {
+			if (track && sub[l] == Gm.mlast && left[l] > 0) {
+				if (first) {
+					if (left[l] != Gm.sl + 1) { fprintf(stderr, "score walk not on the last query row\n"); exit(2); }
+					Rf[l] = gdw_track_to_slot(L[l], Gm.sl);
+				} else Rf[l] += gdw_cell(L[l].V, Gm.sl) - K.B1;
+			}
+			--left[l];
+		}
+	};
 	for (int n = 0; n <= np; ++n) {
 		for (int rA = 0; rA < P;) {
 			const int jsw = rA >> 4;
 			if (jsw < G) {
 				for (int l = 0; l < 64; ++l) {
 					if (sub[l] != jsw) continue;
-					if (left[l] <= 0 && tid[l] >= 0 && sub[l] == Gm.mlast) {
+					if (tid[l] >= 0 && sub[l] == Gm.mlast) {
+						if (left[l] > 0) { fprintf(stderr, "score handed in before the last row\n"); exit(2); }
 						if (Rf[l] % 8) { fprintf(stderr, "tracker not a multiple of 8\n"); exit(2); }
 						out[tid[l]].score = Rf[l] / 8, out[tid[l]].done = 1;
 					}
@@ -98,6 +153,8 @@ static void emulate_pipe(const std::vector<Pair> &pairs, int np, int qlen, int t
 					left[l] = live ? nvalid[l] : 0;
 					Rf[l] = 0;
 					qaddr[l] = (u32)((n & 1) * Gm.BS + grp[l] * Gm.QS);
+					qb[l] = lds[qaddr[l]];
+					++qaddr[l];
 					prow[l] = 16 * sub[l];
 				}
 				any_tn = false;
@@ -107,49 +164,15 @@ static void emulate_pipe(const std::vector<Pair> &pairs, int np, int qlen, int t
 					fetch(n + 1);
 				}
 			}
-			const int rows_here = P - rA < 16 ? P - rA : 16, r_stop = rA + rows_here;
-			for (bool first = true; rA < r_stop; ++rA, first = false) {
-				u32 qb[64];
-				for (int l = 0; l < 64; ++l) {
-					if (qaddr[l] >= lds.size()) { fprintf(stderr, "LDS read out of range\n"); exit(2); }
-					qb[l] = lds[qaddr[l]];
-					++qaddr[l];
+			const bool track = jsw == Gm.mlast - 1;
+			if (jsw < G && P - rA >= 16) {
+				for (int half = 0; half < 2; ++half) {
+					for (int k = 0; k < 8; ++k) step(rA + k, jsw, half == 0 && k == 0, half, track, k);
+					rA += 8;
 				}
-				for (int l = 0; l < 64; ++l) {
-					WaveRow W;
-					W.r = rA, W.st0 = 0, W.en0 = 0, W.st_ = 0, W.en_ = 0, W.up = 0;
-					W.use_array = 0, W.set_tr = 1, W.ukey = gdw_edge_key(K, rA), W.v1key = W.ukey;
-					W.m_first_valid = 1, W.m_first = sub[l] == 0 ? ~0u : 0u;
-					if (jsw < G) gdw_reset_tr(L[l], K, W);
-					gdp_query_scores(L[l], K, qb[l], any_tn);
-					u32 o[4];
-					if (g_single) gdw_compute<false>(L[l], K, W, pX[l], pV[l], pX2[l], o);
-					else gdw_compute<true>(L[l], K, W, pX[l], pV[l], pX2[l], o);
-					if (left[l] > 0) {
-						if (tid[l] < 0 || prow[l] > Gm.rend) { fprintf(stderr, "store outside an alignment\n"); exit(2); }
-						memcpy(&out[tid[l]].bt[(size_t)prow[l] * row_bytes + 16 * sub[l]], o, 16);
-						memset(&out[tid[l]].written[(size_t)prow[l] * row_bytes + 16 * sub[l]], 1, 16);
-					}
-					++prow[l];
-					L[l].R += gdw_lo(L[l].V[0]) - K.B1;
-				}
-				for (int l = 0; l < 64; ++l) {
-					const int p = (l + 63) & 63;
-					pX[l] = L[p].X[7], pV[l] = L[p].V[7], pX2[l] = L[p].X2[7];
-				}
-				if (first && jsw >= 1 && jsw < G) {
-					int h[64];
-					for (int l = 0; l < 64; ++l) h[l] = gdw_track_handoff(L[(l + 63) & 63]);
-					for (int l = 0; l < 64; ++l)
-						if (sub[l] == jsw) L[l].R = h[l] + gdw_lo(L[l].U[0]);
-				}
-				for (int l = 0; l < 64; ++l) {
-					if (sub[l] == Gm.mlast) {
-						if (left[l] == qlen) Rf[l] = gdw_track_to_slot(L[l], Gm.sl);
-						else if (left[l] > 0 && left[l] < qlen) Rf[l] += gdw_cell(L[l].V, Gm.sl) - K.B1;
-					}
-					--left[l];
-				}
+			} else {
+				const int r_stop = P - rA < 16 ? P : rA + 16;
+				for (bool first = true; rA < r_stop; ++rA, first = false) step(rA, jsw, first, 0, jsw < G ? track : false, jsw < G ? -1 : -2);
 			}
 		}
 	}
