@@ -30,6 +30,7 @@ struct DevBuf {
 	size_t cap = 0;
 };
 
+#define GD_MAX_INFLIGHT 8 // batches in flight per context (gdiet_hip_set_inflight)
 struct gdiet_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -39,7 +40,7 @@ struct gdiet_ctx {
 	int last_mask = 0;
 	DevBuf arena;               // backtrace matrices
 	DevBuf tasks, ids, status;  // per-batch descriptors
-	DevBuf pipes;               // PipeWave records of the batch (ksw_pipe.hip.h)
+	DevBuf pipes, pipe_runs, pipe_dst; // PipeWave / PipeRun records of the batch and the compacted id lists of its runs (ksw_pipe.hip.h)
 	DevBuf qseq, tseq, score, ncig, cigar; // host-API staging
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	// head / tail split of a big DP launch (see gdiet_hip_ksw_extd2_batch_dev)
@@ -57,6 +58,7 @@ struct gdiet_ctx {
 	bool single_affine = false;        // set for the duration of a gdiet_hip_ksw_extz2_batch call: single-affine kernel variants
 	std::vector<int32_t> h_ids;
 	std::vector<PipeWave> h_pipes;
+	std::vector<PipeRun> h_pipe_runs;
 	// per-read mapping path (map_pipeline.hip.h)
 	DevBuf m_sc, m_mv, m_u64, m_seed, m_seedout, m_voteout, m_hitoff, m_hits, m_boxes, m_q, m_t, m_aux, m_cig, m_pack, m_post, m_seedids;
 	DevBuf m_srbox, m_srtab, m_srscan, m_srcand; // device-side box stage of the ShortReads variant (map_pipeline.hip.h)
@@ -79,8 +81,8 @@ struct gdiet_ctx {
 	size_t lane_arena_cap = 0;         // a lane whose batch needs no more backtrace than this works in an arena of its own (set with the depth)
 	bool own_arena = false;            // (lane) the last DP stage did
 	bool shared_sticky = false;        // (lane) a recent batch did not fit a private arena
-	gdiet_ctx *async_lane[4] = {nullptr, nullptr, nullptr, nullptr};
-	bool async_busy[4] = {false, false, false, false};
+	gdiet_ctx *async_lane[GD_MAX_INFLIGHT] = {};
+	bool async_busy[GD_MAX_INFLIGHT] = {};
 	std::mutex async_mu;               // guards the ticket bookkeeping of submit / wait
 	std::vector<void *> open_tickets;  // gdiet_map_ticket* submitted and not yet waited for (joined by gdiet_hip_destroy)
 	std::vector<std::vector<uint8_t>> enc_pool; // host buffers of destroyed read batches, reused by the next uploads
@@ -258,13 +260,13 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	if (ctx->pool) gd_pool_free(ctx->pool), ctx->pool = nullptr;
 	for (gdiet_ctx *c : ctx->children) gdiet_hip_destroy(c);
 	ctx->children.clear();
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < GD_MAX_INFLIGHT; ++i)
 		if (ctx->async_lane[i]) gdiet_hip_destroy(ctx->async_lane[i]), ctx->async_lane[i] = nullptr;
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar,
 	                  &ctx->m_sc, &ctx->m_mv, &ctx->m_u64, &ctx->m_seed, &ctx->m_seedout, &ctx->m_voteout, &ctx->m_hitoff, &ctx->m_hits,
-	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post, &ctx->m_seedids, &ctx->pipes};
+	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post, &ctx->m_seedids, &ctx->pipes, &ctx->pipe_runs, &ctx->pipe_dst};
 	for (DevBuf *b : bufs)
 		if (b->p) (void)hipFree(b->p);
 	if (ctx->h_pin.p) (void)hipHostFree(ctx->h_pin.p);
@@ -342,7 +344,7 @@ extern "C" int gdiet_hip_set_dp_split(gdiet_ctx *ctx, int on)
 {
 	if (!ctx) return GDIET_E_PARAM;
 	ctx->dp_split = on != 0;
-	for (int i = 0; i < 4; ++i) if (ctx->async_lane[i]) ctx->async_lane[i]->dp_split = ctx->dp_split;
+	for (int i = 0; i < GD_MAX_INFLIGHT; ++i) if (ctx->async_lane[i]) ctx->async_lane[i]->dp_split = ctx->dp_split;
 	return GDIET_OK;
 }
 
@@ -604,7 +606,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	static const bool use_pipe = !(getenv("GDIET_SR_PIPE") && atoi(getenv("GDIET_SR_PIPE")) == 0);
 	static const int pipe_np_forced = getenv("GDIET_PIPE_NP") ? atoi(getenv("GDIET_PIPE_NP")) : 0;
 	std::vector<int32_t> pipe_ids;
-	ctx->h_pipes.clear();
+	ctx->h_pipes.clear(), ctx->h_pipe_runs.clear();
 	{
 		const std::vector<int32_t> &v = ids[GD_KIND_WAVE16];
 		size_t i = 0;
@@ -621,16 +623,15 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 					size_t np = pipe_np_forced > 0 ? (size_t)pipe_np_forced : std::max<size_t>(8, (m + geo.NG * slots - 1) / (geo.NG * slots));
 					np = std::min(np, (m + geo.NG - 1) / geo.NG);
 					const size_t n_waves = (m + geo.NG * np - 1) / (geo.NG * np);
-					size_t at = i;
-					for (size_t wv = 0; wv < n_waves; ++wv) { // the run in equal shares (the last wavefronts one alignment per group less)
-						const size_t share = (j - at + (n_waves - wv) - 1) / (n_waves - wv), np_w = (share + geo.NG - 1) / geo.NG;
-						PipeWave W;
-						memset(&W, 0, sizeof(W));
-						W.id_off = (int32_t)pipe_ids.size(), W.qlen = A.qlen, W.tlen = A.tlen, W.np = (int32_t)np_w, W.row_bytes = A.row_bytes;
-						for (size_t k = 0; k < np_w * geo.NG; ++k) pipe_ids.push_back(k < share ? v[at + k] : -1);
-						at += share;
-						ctx->h_pipes.push_back(W);
-					}
+					PipeRun R;
+					memset(&R, 0, sizeof(R));
+					R.src_off = (int32_t)pipe_ids.size(), R.dst_off = R.src_off, R.m = (int32_t)m, R.wave_off = (int32_t)ctx->h_pipes.size(), R.n_waves = (int32_t)n_waves, R.ng = geo.NG;
+					for (size_t k = i; k < j; ++k) pipe_ids.push_back(v[k]);
+					PipeWave W; // (id_off, cnt, np: pipe_compact_kernel, once the pre-filter has answered)
+					memset(&W, 0, sizeof(W));
+					W.qlen = A.qlen, W.tlen = A.tlen, W.row_bytes = A.row_bytes;
+					ctx->h_pipes.insert(ctx->h_pipes.end(), n_waves, W);
+					ctx->h_pipe_runs.push_back(R);
 					i = j;
 					continue;
 				}
@@ -652,7 +653,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		id_off[k] = ctx->h_ids.size();
 		if (k == GD_KIND_WAVE16) {
 			for (int g = 0; g < 3; ++g) group_off[g] = ctx->h_ids.size(), ctx->h_ids.insert(ctx->h_ids.end(), groups[g].begin(), groups[g].end());
-			for (PipeWave &W : ctx->h_pipes) W.id_off += (int32_t)ctx->h_ids.size(); // (relative to the batch's whole id list from here on)
+			for (PipeRun &R : ctx->h_pipe_runs) R.src_off += (int32_t)ctx->h_ids.size(); // (relative to the batch's whole id list from here on)
 			ctx->h_ids.insert(ctx->h_ids.end(), pipe_ids.begin(), pipe_ids.end());
 			if (!ctx->h_pipes.empty()) ctx->last_mask |= 16;
 		} else ctx->h_ids.insert(ctx->h_ids.end(), ids[k].begin(), ids[k].end());
@@ -683,7 +684,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		if (rc == GDIET_E_NOMEM) {
 			gdiet_ctx *owner = ctx->parent ? ctx->parent : ctx;
 			std::lock_guard<std::mutex> guard(owner->async_mu); // async_busy[] belongs to submit / wait
-			for (int i = 0; i < 4; ++i) {
+			for (int i = 0; i < GD_MAX_INFLIGHT; ++i) {
 				gdiet_ctx *c = owner->async_lane[i];
 				if (c && c != ctx && !owner->async_busy[i] && c->arena.p) { (void)hipFree(c->arena.p); c->arena.p = nullptr, c->arena.cap = 0, freed = true; }
 			}
@@ -698,7 +699,10 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	GD_HIP(hipMemcpyAsync(ctx->ids.p, ctx->h_ids.data(), sizeof(int32_t) * ctx->h_ids.size(), hipMemcpyHostToDevice, stream));
 	if (!ctx->h_pipes.empty()) {
 		if ((rc = gd_grow(ctx, ctx->pipes, sizeof(PipeWave) * ctx->h_pipes.size()))) return rc;
+		if ((rc = gd_grow(ctx, ctx->pipe_runs, sizeof(PipeRun) * ctx->h_pipe_runs.size()))) return rc;
+		if ((rc = gd_grow(ctx, ctx->pipe_dst, sizeof(int32_t) * pipe_ids.size()))) return rc;
 		GD_HIP(hipMemcpyAsync(ctx->pipes.p, ctx->h_pipes.data(), sizeof(PipeWave) * ctx->h_pipes.size(), hipMemcpyHostToDevice, stream));
+		GD_HIP(hipMemcpyAsync(ctx->pipe_runs.p, ctx->h_pipe_runs.data(), sizeof(PipeRun) * ctx->h_pipe_runs.size(), hipMemcpyHostToDevice, stream));
 	}
 
 	const KswTask *d_tasks = (const KswTask *)ctx->tasks.p;
@@ -751,7 +755,10 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		gd_launch_wave_groups<16>(d_tasks, d_ids + group_off[0], (int)(groups[0].size() / 4), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
 		gd_launch_wave_groups<10>(d_tasks, d_ids + group_off[1], (int)(groups[1].size() / 6), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
 		gd_launch_wave_groups<8>(d_tasks, d_ids + group_off[2], (int)(groups[2].size() / 8), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single, g_nc, g_cg);
-		gd_launch_pipe(d_tasks, d_ids, (const PipeWave *)ctx->pipes.p, (int)ctx->h_pipes.size(), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
+		int max_run = 0;
+		for (const PipeRun &R : ctx->h_pipe_runs) max_run = std::max(max_run, (int)R.m);
+		gd_launch_pipe(d_tasks, d_ids, (PipeRun *)ctx->pipe_runs.p, (int)ctx->h_pipe_runs.size(), max_run, (int32_t *)ctx->pipe_dst.p, (PipeWave *)ctx->pipes.p,
+		               (int)ctx->h_pipes.size(), d_qseq, d_tseq, d_bt, d_status, d_score, K, stream, single);
 	}
 	if (!ids[GD_KIND_WAVE128].empty()) {
 		// few wide-band alignments (the arena bounds how many 50 kbp ONT alignments fit): two wavefronts share one, halving the
@@ -836,7 +843,7 @@ extern "C" int gdiet_hip_last_kernel_ms(gdiet_ctx *ctx, float *dp_ms, float *bt_
 static bool gd_tickets_open(gdiet_ctx *ctx)
 {
 	std::lock_guard<std::mutex> guard(ctx->async_mu);
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < GD_MAX_INFLIGHT; ++i)
 		if (ctx->async_busy[i]) { ctx->err = "batches submitted with gdiet_hip_map_submit are still in flight: wait for their tickets first"; return true; }
 	return false;
 }

@@ -13,8 +13,62 @@
 #include "ksw_wave.hip.h"
 #include "ksw_pipe_core.h"
 
-// one wavefront's work: np alignments per group, ids at task_ids[id_off + n * NG + g] (-1: none), all of geometry qlen x tlen
-struct PipeWave { int32_t id_off, qlen, tlen, np, row_bytes, pad[3]; };
+// one wavefront's work: cnt alignments of geometry qlen x tlen, np = ceil(cnt / NG) per group, alignment n of group g = ids[id_off + n * NG + g]
+struct PipeWave { int32_t id_off, qlen, tlen, np, row_bytes, cnt, pad[2]; };
+// A run of alignments of one geometry = n_waves consecutive PipeWave records.  The planner (host) knows which alignments the run has, not
+// which of them the exact-match pre-filter will answer (22 % of a 1 %-error short-read batch): pipe_compact_kernel, between the
+// pre-filter and the DP, keeps the ids that are still pending and deals them out to the run's wavefronts in equal shares -- a slot of a
+// pipe that holds an answered alignment would cost its qlen + 15 steps all the same.
+struct PipeRun { int32_t src_off, m, dst_off, wave_off, n_waves, ng, count, done; }; // count / done: zero when uploaded, the kernel's counters
+
+// Blocks of GDP_COMPACT_THREADS x GDP_COMPACT_ITEMS ids each, grid (chunks of the longest run, runs).  The order of a run's alignments
+// does not matter (every alignment is computed on its own), so a wavefront reserves room for its pending ids with one atomic add on the
+// run's counter; the block that finishes last deals the run out to its wavefronts.
+#define GDP_COMPACT_THREADS 256
+#define GDP_COMPACT_ITEMS 8
+__global__ __launch_bounds__(GDP_COMPACT_THREADS) void pipe_compact_kernel(PipeRun *__restrict__ runs, const int32_t *__restrict__ ids,
+                                                                         const int32_t *__restrict__ status, int32_t *__restrict__ dst, PipeWave *__restrict__ pipes)
+{
+	__shared__ int s_last;
+	PipeRun &R = runs[blockIdx.y];
+	const int m = R.m, per_block = GDP_COMPACT_THREADS * GDP_COMPACT_ITEMS, n_chunks = (m + per_block - 1) / per_block;
+	if ((int)blockIdx.x >= n_chunks) return;
+	const int lane = threadIdx.x & 63;
+	const int32_t *src = ids + R.src_off;
+	int32_t *out = dst + R.dst_off;
+	int id[GDP_COMPACT_ITEMS], live[GDP_COMPACT_ITEMS], mine = 0;
+	const int first = (int)blockIdx.x * per_block + (int)threadIdx.x * GDP_COMPACT_ITEMS;
+#pragma unroll
+	for (int k = 0; k < GDP_COMPACT_ITEMS; ++k) id[k] = first + k < m ? src[first + k] : -1;
+#pragma unroll
+	for (int k = 0; k < GDP_COMPACT_ITEMS; ++k) live[k] = id[k] >= 0 && status[id[k]] == GD_ST_PENDING, mine += live[k];
+	int incl = mine; // inclusive prefix over the wavefront
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const int v = __shfl_up(incl, d, 64);
+		if (lane >= d) incl += v;
+	}
+	int base = 0;
+	if (lane == 63 && incl) base = atomicAdd(&R.count, incl);
+	base = __shfl(base, 63, 64);
+	int at = base + incl - mine;
+#pragma unroll
+	for (int k = 0; k < GDP_COMPACT_ITEMS; ++k)
+		if (live[k]) out[at++] = id[k];
+	// the last block of the run: equal shares, the first (total mod n_waves) wavefronts one alignment more
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0) s_last = atomicAdd(&R.done, 1) == n_chunks - 1;
+	__syncthreads();
+	if (!s_last) return;
+	__threadfence();
+	const int total = atomicAdd(&R.count, 0), q = total / R.n_waves, rem = total % R.n_waves;
+	for (int w = threadIdx.x; w < R.n_waves; w += GDP_COMPACT_THREADS) {
+		const int cnt = q + (w < rem), a0 = w * q + (w < rem ? w : rem);
+		PipeWave &W = pipes[R.wave_off + w];
+		W.id_off = R.dst_off + a0, W.cnt = cnt, W.np = (cnt + R.ng - 1) / R.ng;
+	}
+}
 
 // Four wavefronts per workgroup, each with a pipe and an LDS region of its own and no barrier between them: the dispatcher then puts one
 // on each SIMD of a CU (single-wavefront workgroups were spread unevenly: 2 743 of 3 922 wavefronts resident on average, the kernel as
@@ -33,7 +87,7 @@ __global__ __launch_bounds__(64 * GDP_BLOCK_WAVES) __attribute__((amdgpu_waves_p
 	const int pw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * GDP_BLOCK_WAVES + wv);
 	if (pw >= n_pipes) return;
 	uint8_t *const lds = lds_all[wv];
-	const int id_off = __builtin_amdgcn_readfirstlane(pipes[pw].id_off), np = __builtin_amdgcn_readfirstlane(pipes[pw].np);
+	const int id_off = __builtin_amdgcn_readfirstlane(pipes[pw].id_off), np = __builtin_amdgcn_readfirstlane(pipes[pw].np), cnt = __builtin_amdgcn_readfirstlane(pipes[pw].cnt);
 	const int row_bytes = __builtin_amdgcn_readfirstlane(pipes[pw].row_bytes);
 	const PipeGeo Gm = gd_pipe_geo(__builtin_amdgcn_readfirstlane(pipes[pw].qlen), __builtin_amdgcn_readfirstlane(pipes[pw].tlen));
 	const int G = Gm.G, NG = Gm.NG, P = Gm.P, qlen = Gm.qlen, tlen = Gm.tlen;
@@ -50,7 +104,7 @@ __global__ __launch_bounds__(64 * GDP_BLOCK_WAVES) __attribute__((amdgpu_waves_p
 	auto fetch = [&](const int nn) __attribute__((always_inline)) {
 		int tid_ = -1, live_ = 0;
 		int64_t qo = 0, to = 0, bo = 0;
-		if (!spare && nn < np) tid_ = task_ids[id_off + nn * NG + grp];
+		if (!spare && nn * NG + grp < cnt) tid_ = task_ids[id_off + nn * NG + grp];
 		if (tid_ >= 0) {
 			live_ = status[tid_] == GD_ST_PENDING; // (else the exact-match pre-filter answered this one)
 			qo = tasks[tid_].qoff, to = tasks[tid_].toff, bo = tasks[tid_].bt_off;
@@ -190,13 +244,22 @@ __global__ __launch_bounds__(64 * GDP_BLOCK_WAVES) __attribute__((amdgpu_waves_p
 	}
 }
 
-static inline void gd_launch_pipe(const KswTask *tasks, const int32_t *ids, const PipeWave *pipes, int n_pipes, const uint8_t *q, const uint8_t *t,
-                                  uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, bool single)
+// ids: the batch's id list (the runs' alignments as the planner listed them); dst: room for as many ids as the runs hold
+static inline void gd_launch_pipe(const KswTask *tasks, const int32_t *all_ids, PipeRun *runs, int n_runs, int max_run, int32_t *dst, PipeWave *pipes, int n_pipes,
+                                  const uint8_t *q, const uint8_t *t, uint8_t *bt, int32_t *status, int32_t *score, KswConst C, hipStream_t s, bool single)
 {
-	if (n_pipes <= 0) return;
+	if (n_pipes <= 0 || n_runs <= 0) return;
+	const int per_block = GDP_COMPACT_THREADS * GDP_COMPACT_ITEMS;
+	hipLaunchKernelGGL(pipe_compact_kernel, dim3((max_run + per_block - 1) / per_block, n_runs), dim3(GDP_COMPACT_THREADS), 0, s, runs, all_ids, status, dst, pipes);
+	const int32_t *ids = dst;
 	WaveK K;
 	gdw_make_consts(C, K);
 	const dim3 grid((n_pipes + GDP_BLOCK_WAVES - 1) / GDP_BLOCK_WAVES), block(64 * GDP_BLOCK_WAVES);
-	if (single) hipLaunchKernelGGL((ksw_extd2_pipe_kernel<false>), grid, block, 0, s, tasks, ids, pipes, n_pipes, q, t, bt, status, score, K);
-	else hipLaunchKernelGGL((ksw_extd2_pipe_kernel<true>), grid, block, 0, s, tasks, ids, pipes, n_pipes, q, t, bt, status, score, K);
+	// GDIET_PIPE_WAVES = 3 / 2: at most that many wavefronts of this kernel per SIMD (a workgroup puts one on each SIMD of its CU; an unused
+	// dynamic LDS allocation caps the workgroups per CU), the registers of the fourth stay free for the other kernels of the batches in flight
+	static const int cap_waves = getenv("GDIET_PIPE_WAVES") ? atoi(getenv("GDIET_PIPE_WAVES")) : 4;
+	size_t lds = 0;
+	if (cap_waves == 2 || cap_waves == 3) lds = (size_t)(160 * 1024) / (cap_waves + 1) + 1024 - (size_t)GDP_BLOCK_WAVES * 2 * GDP_BUF_BYTES;
+	if (single) hipLaunchKernelGGL((ksw_extd2_pipe_kernel<false>), grid, block, lds, s, tasks, ids, pipes, n_pipes, q, t, bt, status, score, K);
+	else hipLaunchKernelGGL((ksw_extd2_pipe_kernel<true>), grid, block, lds, s, tasks, ids, pipes, n_pipes, q, t, bt, status, score, K);
 }

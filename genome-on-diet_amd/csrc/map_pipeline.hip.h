@@ -344,7 +344,6 @@ static void gd_opt_from_c(const gdiet_mapopt_t *o, const gdiet_index *ix, GdMapO
 	O.af_max_loc = o->AF_max_loc;
 }
 
-#define GD_MAX_INFLIGHT 4
 static void gd_drop_async_lanes(gdiet_ctx *ctx)
 {
 	for (int i = 0; i < GD_MAX_INFLIGHT; ++i)
@@ -975,7 +974,7 @@ extern "C" int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *ix, con
 	gd_opt_from_c(copt, ix, O);
 	{ const int rc = gd_check_opt(ctx, O); if (rc) return rc; }
 	ctx->last_was_async = false;
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < GD_MAX_INFLIGHT; ++i)
 		if (ctx->async_busy[i]) { ctx->err = "batches submitted with gdiet_hip_map_submit are still in flight"; return GDIET_E_PARAM; }
 
 	const int lanes = std::max(1, std::min(ctx->map_lanes, (n + 255) / 256));
@@ -1167,7 +1166,7 @@ extern "C" int gdiet_hip_seed_batch(gdiet_ctx *ctx, const gdiet_index *ix, const
 	seed_off[0] = occ_off[0] = 0;
 	if (n == 0) return GDIET_OK;
 	(void)hipSetDevice(ctx->device);
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < GD_MAX_INFLIGHT; ++i)
 		if (ctx->async_busy[i]) { ctx->err = "batches submitted with gdiet_hip_map_submit are still in flight"; return GDIET_E_PARAM; }
 	GdMapOpt O;
 	gd_opt_from_c(copt, ix, O);

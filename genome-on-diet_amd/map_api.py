@@ -342,7 +342,7 @@ class Mapper:
         self.ctx._check(self.lib.gdiet_hip_set_inflight(self.ctx._h, n))
 
     def submit(self, batch):
-        """start mapping a resident batch (gdiet_hip_map_submit); returns a ticket for wait().  At most set_inflight() tickets (default 2, at most 4) may be open."""
+        """start mapping a resident batch (gdiet_hip_map_submit); returns a ticket for wait().  At most set_inflight() tickets (default 2, at most 8) may be open."""
         h, n = batch
         n_regs = (C.c_int32 * n)()
         regs = (C.POINTER(Reg) * n)()

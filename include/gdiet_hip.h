@@ -313,7 +313,7 @@ int gdiet_hip_map_uploaded(gdiet_ctx *ctx, const gdiet_index *idx, const gdiet_m
 void gdiet_hip_batch_destroy(gdiet_ctx *ctx, gdiet_read_batch *batch);
 /* Several batches in flight: _submit starts the whole path for a resident batch on a lane of its own (stream, scratch) and
  * returns a ticket, _wait joins it (results in the n_regs / regs arrays given to _submit).  Up to
- * gdiet_hip_set_inflight() tickets (default 2, at most 4) may be open; wait for them in submission order.  The latency-bound
+ * gdiet_hip_set_inflight() tickets (default 2, at most 8) may be open; wait for them in submission order.  The latency-bound
  * stages of one batch overlap the DP kernel of another, exactly as the reference's kt_pipeline overlaps the steps of consecutive
  * mini-batches (LR/map.c:2094-2170); results are those of gdiet_hip_map_uploaded.  The lanes share one backtrace arena (~34 MB
  * per 15 kbp alignment: two whole-batch arenas would not fit in HBM), so their DP stages take turns -- unless a batch's backtrace

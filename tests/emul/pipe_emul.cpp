@@ -22,7 +22,7 @@ struct EmuOut { int score = GD_NEG_INF, done = 0; std::vector<uint8_t> bt, writt
 static bool g_single = false;
 
 // one wavefront: NG groups x np alignments (pairs[n * NG + g]; live == 0: the pre-filter answered it, never touched), geometry qlen x tlen
-static void emulate_pipe(const std::vector<Pair> &pairs, int np, int qlen, int tlen, int row_bytes, const KswConst &C, std::vector<EmuOut> &out)
+static void emulate_pipe(const std::vector<Pair> &pairs, int np, int cnt, int qlen, int tlen, int row_bytes, const KswConst &C, std::vector<EmuOut> &out)
 {
 	WaveK K;
 	if (!gdw_make_consts(C, K)) { fprintf(stderr, "consts rejected\n"); exit(2); }
@@ -41,7 +41,7 @@ static void emulate_pipe(const std::vector<Pair> &pairs, int np, int qlen, int t
 	auto fetch = [&](const int nn) {
 		for (int l = 0; l < 64; ++l) {
 			if (spare[l]) continue;
-			const int id = nn < np ? nn * NG + grp[l] : -1;
+			const int id = nn * NG + grp[l] < cnt ? nn * NG + grp[l] : -1; // (cnt: the wavefront's share of its run; the last alignments of a group may be missing)
 			const Pair *pr = id >= 0 ? &pairs[id] : nullptr;
 			const int tid_ = pr && !pr->q.empty() ? id : -1; // (an empty pair: the -1 padding of the id table)
 			const int live_ = tid_ >= 0 && pr->live;
@@ -250,7 +250,8 @@ int main(int argc, char **argv)
 		C.long_thres = C.e != C.e2 ? (C.q2 - C.q) / (C.e - C.e2) - 1 : 0;
 		if (C.q2 + C.e2 + C.long_thres * C.e2 > C.q + C.e + C.long_thres * C.e) ++C.long_thres;
 		C.long_diff = C.long_thres * (C.e - C.e2) - (C.q2 - C.q) - C.e2;
-		std::vector<Pair> pairs((size_t)np * Gm.NG);
+		const int cnt = np * Gm.NG - (int)(g() % Gm.NG); // np = ceil(cnt / NG)
+		std::vector<Pair> pairs((size_t)cnt);
 		for (size_t i = 0; i < pairs.size(); ++i) {
 			Pair &p = pairs[i];
 			const unsigned kind = g() % 16;
@@ -265,7 +266,7 @@ int main(int argc, char **argv)
 			p.live = kind != 1; // kind 1: answered by the exact-match pre-filter -- the kernel must leave it alone
 		}
 		std::vector<EmuOut> out;
-		emulate_pipe(pairs, np, qlen, tlen, row_bytes, C, out);
+		emulate_pipe(pairs, np, cnt, qlen, tlen, row_bytes, C, out);
 		int8_t mat[25];
 		for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? Pz[0] : -Pz[1]);
 		for (size_t i = 0; i < pairs.size(); ++i) {
