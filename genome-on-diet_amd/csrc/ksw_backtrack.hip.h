@@ -42,8 +42,17 @@ __global__ __launch_bounds__(64) void ksw_exact_match_kernel(const KswTask *__re
 	int st = GD_ST_PENDING;
 	if (T.exact_score != GD_NEG_INF && T.qlen == T.tlen && T.qlen > 0) {
 		const uint8_t *q = qseq + T.qoff, *t = tseq + T.toff;
+		// eight bases per load and compare (the windows sit at arbitrary byte offsets of the packed buffers: loads through memcpy, which the
+		// compiler may turn into unaligned 8-byte accesses where the target allows them), the tail byte by byte; a thread stops at its first
+		// difference
 		bool eq = true;
-		for (int k = 0; k < T.qlen; ++k) eq &= q[k] == t[k];
+		int k = 0;
+		for (; eq && k + 8 <= T.qlen; k += 8) {
+			uint64_t a, b;
+			__builtin_memcpy(&a, q + k, 8), __builtin_memcpy(&b, t + k, 8);
+			eq = a == b;
+		}
+		for (; eq && k < T.qlen; ++k) eq = q[k] == t[k];
 		if (eq) {
 			st = GD_ST_EXACT;
 			score[tid] = T.exact_score;
