@@ -370,6 +370,8 @@ static int gd_generic_cap(int qlen, int tlen, int w)
 static inline size_t gd_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static const int gd_group_lanes = getenv("GDIET_GROUP_LANES") ? atoi(getenv("GDIET_GROUP_LANES")) : 0; // 16: always four alignments per wavefront
+// GDIET_SR_PIPE=0: no skewed pipelines (ksw_pipe.hip.h), short alignments on the grouped kernels only
+static const bool gd_use_pipe = !(getenv("GDIET_SR_PIPE") && atoi(getenv("GDIET_SR_PIPE")) == 0);
 
 // decide kernel + backtrace geometry of one alignment
 static void gd_plan_one(int mode, bool wave_scoring_ok, int qlen, int tlen, int w, int32_t &kind, int32_t &row_bytes)
@@ -386,6 +388,7 @@ static void gd_plan_one(int mode, bool wave_scoring_ok, int qlen, int tlen, int 
 			const int g = gd_group_lanes == 16 ? 16 : tlen <= 128 ? 8 : tlen <= 160 ? 10 : 16;
 			kind = GD_KIND_WAVE16, row_bytes = g * 16;
 		}
+		else if (gd_use_pipe && gd_pipe_geometry_ok(qlen, tlen, w)) kind = GD_KIND_WAVE16, row_bytes = 16 * 16; // 241..256 bases, full matrix: one block more than the 16-lane groups hold -- the pipelines take it (every run, however short)
 		else kind = GD_KIND_WAVE64, row_bytes = 64 * 16;
 	} else if (gd_wave_supported(qlen, tlen, w, 128)) kind = GD_KIND_WAVE128; // row_bytes stays n_col_*16
 }
@@ -603,7 +606,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	// Full matrices (a short-read batch: w >= both lengths) of one geometry, enough of them to keep every group of a wavefront busy for a
 	// few alignments, run as skewed pipelines instead (ksw_pipe.hip.h): a wavefront takes np alignments per group, sized so that the
 	// run fills the GPU's wavefront slots once.  GDIET_SR_PIPE=0 keeps the grouped kernels; GDIET_PIPE_NP forces np.
-	static const bool use_pipe = !(getenv("GDIET_SR_PIPE") && atoi(getenv("GDIET_SR_PIPE")) == 0);
+	const bool use_pipe = gd_use_pipe;
 	static const int pipe_np_forced = getenv("GDIET_PIPE_NP") ? atoi(getenv("GDIET_PIPE_NP")) : 0;
 	std::vector<int32_t> pipe_ids;
 	ctx->h_pipes.clear(), ctx->h_pipe_runs.clear();
@@ -618,7 +621,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 				       gd_pipe_geometry_ok(A.qlen, A.tlen, h_tasks[v[j]].w)) ++j;
 				const PipeGeo geo = gd_pipe_geo(A.qlen, A.tlen);
 				const size_t m = j - i;
-				if (m >= (size_t)(2 * geo.NG)) {
+				if (m >= (size_t)(2 * geo.NG) || !gd_wave_supported(A.qlen, A.tlen, A.w, 16)) { // (the second: nothing else takes it, see gd_plan_one)
 					// (four wavefronts of this kernel per SIMD; a lane of a context with batches in flight plans for half of them: two batches' kernels
 					// then share the GPU, and the longer pipes lose less to filling and draining -- 26.4 -> 28.7 M reads/s with eight batches in flight)
 					const size_t slots = (size_t)(ctx->wave_slots / 5 * 4) / (ctx->parent ? 2 : 1);

@@ -32,13 +32,13 @@ struct PipeGeo {
 };
 #define GDP_BUF_BYTES 3584 // the largest BS (G == 2: 32 groups of 64 + 32 + 16 bytes)
 
-// Does the pipeline take this geometry?  Full matrix (the band terms of SR/ksw2_extd2_sse.c:138-141 never bind), a target of 17..160
-// bases (2..10 blocks), lengths close enough for "at most two alignments in flight per group" and for the padded query buffer.
+// Does the pipeline take this geometry?  Full matrix (the band terms of SR/ksw2_extd2_sse.c:138-141 never bind), a target of 17..256
+// bases (2..16 blocks), lengths close enough for "at most two alignments in flight per group" and for the padded query buffer.
 static inline __host__ __device__ bool gd_pipe_geometry_ok(int qlen, int tlen, int w)
 {
 	if (w < 0) w = tlen > qlen ? tlen : qlen;
-	if (tlen < 17 || tlen > 160 || qlen < 17) return false;
-	if (w < qlen || w < tlen) return false;
+	if (tlen < 17 || tlen > 256 || qlen < 17) return false;
+	if (w < qlen - 1 || w < tlen - 1) return false; // (exactly the bands that never bind: tests/emul/pipe_emul.cpp compares every row; a 151-base read at bw = 150 is one)
 	return qlen - tlen <= 15 && tlen - qlen <= 15;
 }
 

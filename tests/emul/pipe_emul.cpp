@@ -235,14 +235,15 @@ int main(int argc, char **argv)
 	int n_run = 0, n_bad = 0, n_geo_refused = 0;
 	for (int it = 0; it < n_pipes; ++it) {
 		const int *Pz = presets[it % 3];
-		int tlen = it % 3 == 0 ? 150 : 17 + g() % 144, qlen = it % 3 == 0 ? 150 : tlen + (int)(g() % 31) - 15;
+		int tlen = it % 3 == 0 ? 150 : 17 + g() % 240, qlen = it % 3 == 0 ? 150 : tlen + (int)(g() % 31) - 15;
 		if (qlen < 17) qlen = 17;
 		const int wmax = tlen > qlen ? tlen : qlen;
-		const int w = it % 4 == 1 ? -1 : wmax + g() % 60;
+		const int w = it % 4 == 1 ? -1 : it % 4 == 2 ? wmax - 1 : wmax + g() % 60; // (wmax - 1: the narrowest band that never binds)
+		if (gd_pipe_geometry_ok(qlen, tlen, wmax - 2)) { fprintf(stderr, "a band that binds was admitted\n"); return 2; }
 		if (!gd_pipe_geometry_ok(qlen, tlen, w)) { ++n_geo_refused; continue; }
 		const PipeGeo Gm = gd_pipe_geo(qlen, tlen);
-		if (16 * (Gm.G - 1) >= Gm.P || Gm.QS < Gm.P + 1 || Gm.G < 2 || Gm.G > 10) { fprintf(stderr, "geometry invariants\n"); return 2; }
-		const int np = 1 + g() % 5, row_bytes = 16 * (tlen <= 128 ? 8 : 10); // (the planner's row stride: that of the 8- / 10-lane groups)
+		if (16 * (Gm.G - 1) >= Gm.P || Gm.QS < Gm.P + 1 || Gm.G < 2 || Gm.G > 16) { fprintf(stderr, "geometry invariants\n"); return 2; }
+		const int np = 1 + g() % 5, row_bytes = 16 * (tlen <= 128 ? 8 : tlen <= 160 ? 10 : 16); // (the planner's row stride: that of the 8- / 10- / 16-lane groups)
 		KswConst C;
 		C.q = Pz[2], C.e = Pz[3], C.q2 = g_single ? Pz[2] : Pz[4], C.e2 = g_single ? Pz[3] : Pz[5];
 		if (C.q2 + C.e2 < C.q + C.e) std::swap(C.q, C.q2), std::swap(C.e, C.e2);

@@ -142,14 +142,17 @@ def test_short_read_quartets_match_oracle(gpu_ctx, pkg, oracle):
 
 def test_short_read_pipelines_match_oracle(gpu_ctx, pkg, oracle):
     """full matrices of one geometry as skewed pipelines (ksw_extd2_pipe_kernel: a lane starts the group's next alignment as soon as its
-    block has left the matrix): 2 to 10 lanes per alignment, qlen on both sides of tlen, runs that end inside a wavefront's share,
+    block has left the matrix): 2 to 16 lanes per alignment, qlen on both sides of tlen, runs that end inside a wavefront's share,
     exact-match rows (answered by the pre-filter: their slot of the pipe stays silent), Ns, and heavy error rates whose best paths
     use the whole matrix -- against the oracle; the other geometries of the batch stay on the grouped kernels"""
     gdo, lib = oracle
     rng = np.random.default_rng(515)
     qs, ts, ws = [], [], []
     geos = [(150, 150, 150, 333), (150, 150, 171, 40), (17, 17, 20, 70), (36, 49, 49, 77), (128, 114, 128, 90), (100, 100, 150, 64), (160, 160, 160, 29),
-            (155, 145, 200, 50), (59, 66, 72, 130), (33, 48, 48, 25), (150, 151, 151, 13)]
+            (155, 145, 200, 50), (59, 66, 72, 130), (33, 48, 48, 25), (150, 151, 151, 13),
+            (151, 151, 150, 100),  # a 151-base read at bw = 150: the narrowest band that never binds
+            (250, 250, 250, 50), (241, 256, 256, 9), (245, 245, 244, 1),  # 16 blocks: beyond the grouped kernels -- pipelines however short the run
+            (200, 200, 199, 30)]
     for ql, tl, w, cnt in geos:
         for i in range(cnt):
             err = (0.01, 0.002) if i % 3 == 0 else (0.05, 0.02) if i % 3 == 1 else (0.15, 0.06)
