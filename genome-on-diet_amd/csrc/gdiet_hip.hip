@@ -622,11 +622,17 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 				const PipeGeo geo = gd_pipe_geo(A.qlen, A.tlen);
 				const size_t m = j - i;
 				if (m >= (size_t)(2 * geo.NG) || !gd_wave_supported(A.qlen, A.tlen, A.w, 16)) { // (the second: nothing else takes it, see gd_plan_one)
-					// (four wavefronts of this kernel per SIMD; a lane of a context with batches in flight plans for half of them: two batches' kernels
-					// then share the GPU, and the longer pipes lose less to filling and draining -- 26.4 -> 28.7 M reads/s with eight batches in flight)
-					const size_t slots = (size_t)(ctx->wave_slots / 5 * 4) / (ctx->parent ? 2 : 1);
-					size_t np = pipe_np_forced > 0 ? (size_t)pipe_np_forced : std::max<size_t>(8, (m + geo.NG * slots - 1) / (geo.NG * slots));
-					np = std::min(np, (m + geo.NG - 1) / geo.NG);
+					// Alignments per group of a wavefront.  The kernel has 4 wavefront slots per SIMD.  A batch on its own (synchronous call): one
+					// round of wavefronts over 70 % of the slots (100 000 pairs: np 6 -> 2.18 ms, 8 -> 2.48; 12 000 pairs: np 1 -> 0.30 ms,
+					// 8 -> 0.84 -- a short run wants many short pipes, filling and draining is cheaper than an empty GPU).  A lane of a context
+					// with batches in flight: half of the slots and at least 8 per group -- two batches' kernels share the GPU, and the longer
+					// pipes lose less to filling and draining (26.4 -> 28.7 M reads/s with eight batches in flight) -- but never fewer than 256 wavefronts.
+					const size_t all_slots = (size_t)(ctx->wave_slots / 5 * 4), groups = (m + geo.NG - 1) / geo.NG;
+					size_t np;
+					if (pipe_np_forced > 0) np = (size_t)pipe_np_forced;
+					else if (!ctx->parent) np = std::max<size_t>(1, (groups + all_slots * 7 / 10 - 1) / (all_slots * 7 / 10));
+					else np = std::min(std::max<size_t>(8, (groups + all_slots / 2 - 1) / (all_slots / 2)), std::max<size_t>(1, groups / 256));
+					np = std::min(np, groups);
 					const size_t n_waves = (m + geo.NG * np - 1) / (geo.NG * np);
 					PipeRun R;
 					memset(&R, 0, sizeof(R));
