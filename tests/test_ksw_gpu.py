@@ -1,5 +1,7 @@
 """GPU parity: the HIP ksw_extd2 batch (through the C ABI) against the reference's golden vectors and against the
 oracle on seeded fuzz; plus size-independent properties at HiFi-sized inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -183,6 +185,23 @@ def test_short_read_pipelines_match_oracle(gpu_ctx, pkg, oracle):
         assert sc[i] == o["score"], (i, len(qs[i]), len(ts[i]), ws[i], sc[i], o["score"])
         assert np.array_equal(cg[i], o["cigar"]), (i, len(qs[i]), len(ts[i]), ws[i])
     assert n_exact >= 20
+
+
+def test_pipelines_and_grouped_kernels_agree_at_scale():
+    """120 000 short-read-shaped pairs (a short-read batch's size per GPU wavefront slot; a quarter exact matches, which the device-side
+    compaction drops from the pipes) through the skewed pipelines and, in a second process with GDIET_SR_PIPE=0, through the grouped
+    kernels: one digest over every score and CIGAR (tests/pipe_digest_check.py).  The grouped kernels are pinned to the oracle and the
+    reference's goldens by the tests around this one; this is the same comparison at a size the oracle would need minutes for."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pipe_digest_check.py")
+    outs = []
+    for env in ({}, {"GDIET_SR_PIPE": "0"}):
+        r = subprocess.run([sys.executable, script], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0 and "digest" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+        outs.append(r.stdout.strip().split("\n")[-1].split())
+    assert int(outs[0][1]) & 16 and not int(outs[1][1]) & 16, outs  # the first run used the pipelines, the second did not
+    assert outs[0][-1] == outs[1][-1], outs
 
 
 def test_short_read_group_widths_match_oracle(gpu_ctx, pkg, oracle):
