@@ -40,6 +40,7 @@ struct gdiet_ctx {
 	int last_mask = 0;
 	DevBuf arena;               // backtrace matrices
 	DevBuf tasks, ids, status;  // per-batch descriptors
+	DevBuf diag;                // per-alignment score of the main diagonal (ksw_exact_match_kernel -> ksw_backtrack_kernel)
 	DevBuf pipes, pipe_runs, pipe_dst; // PipeWave / PipeRun records of the batch and the compacted id lists of its runs (ksw_pipe.hip.h)
 	DevBuf qseq, tseq, score, ncig, cigar; // host-API staging
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -266,7 +267,7 @@ extern "C" void gdiet_hip_destroy(gdiet_ctx *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	DevBuf *bufs[] = {&ctx->arena, &ctx->tasks, &ctx->ids, &ctx->status, &ctx->qseq, &ctx->tseq, &ctx->score, &ctx->ncig, &ctx->cigar,
 	                  &ctx->m_sc, &ctx->m_mv, &ctx->m_u64, &ctx->m_seed, &ctx->m_seedout, &ctx->m_voteout, &ctx->m_hitoff, &ctx->m_hits,
-	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post, &ctx->m_seedids, &ctx->pipes, &ctx->pipe_runs, &ctx->pipe_dst};
+	                  &ctx->m_boxes, &ctx->m_q, &ctx->m_t, &ctx->m_aux, &ctx->m_cig, &ctx->m_pack, &ctx->m_post, &ctx->m_seedids, &ctx->pipes, &ctx->pipe_runs, &ctx->pipe_dst, &ctx->diag};
 	for (DevBuf *b : bufs)
 		if (b->p) (void)hipFree(b->p);
 	if (ctx->h_pin.p) (void)hipHostFree(ctx->h_pin.p);
@@ -723,8 +724,15 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 
 	if (arena_free) GD_HIP(hipStreamWaitEvent(stream, arena_free, 0)); // descriptors are across; only the kernels queue behind the arena's last user
 	GD_HIP(hipEventRecord(ctx->ev[0], stream));
+	// (GDIET_DIAG_SHORTCUT=0: every short alignment is walked back, also those whose score says the walk stays on the main diagonal)
+	static const bool diag_shortcut = !(getenv("GDIET_DIAG_SHORTCUT") && atoi(getenv("GDIET_DIAG_SHORTCUT")) == 0);
+	int32_t *d_diag = nullptr;
+	if (diag_shortcut && !ids[GD_KIND_WAVE16].empty()) {
+		if ((rc = gd_grow(ctx, ctx->diag, sizeof(int32_t) * (size_t)n))) return rc;
+		d_diag = (int32_t *)ctx->diag.p;
+	}
 	hipLaunchKernelGGL(ksw_exact_match_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_qseq, d_tseq,
-	                   d_status, d_score, d_n_cigar, d_cigar);
+	                   d_status, d_score, d_n_cigar, d_cigar, d_diag, (int)K.sc_mch, (int)K.sc_mis);
 	// Head / tail split of a big 64-lane launch.  The grid is sorted longest-first, so the first `wave_slots` alignments start at
 	// once and the rest fill in as slots free up -- it is the latter that finish last.  Launched as two kernels (head on the
 	// caller's stream, tail on a second one), the head's backtrack runs while the tail is still in the DP, and only the tail's
@@ -738,7 +746,8 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	auto backtrack = [&](const int32_t *list, int cnt, hipStream_t st) {
 		if (cnt <= 0) return;
 		if (bt_wave) hipLaunchKernelGGL(ksw_backtrack_wave_kernel, dim3((cnt + 3) / 4), dim3(256), 0, st, d_tasks, cnt, d_bt, d_status, d_score, d_n_cigar, d_cigar, list);
-		else hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((cnt + 63) / 64), dim3(64), 0, st, d_tasks, cnt, d_bt, d_status, d_score, d_n_cigar, d_cigar, 0, list);
+		else hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((cnt + 63) / 64), dim3(64), 0, st, d_tasks, cnt, d_bt, d_status, d_score, d_n_cigar, d_cigar, 0, list,
+		                        (const int32_t *)nullptr, (const int32_t *)d_diag);
 	};
 	ctx->last_split = split;
 	if (split) {

@@ -30,37 +30,48 @@ static inline __host__ __device__ uint32_t gd_bt_decode(uint32_t b)
 	return (4u - (b & 7u)) | ((nb >> 4) & 0x08u) | ((nb >> 2) & 0x10u) | (nb & 0x20u) | ((nb << 2) & 0x40u);
 }
 
+// Pre-filter (exact_match_sse, LR/map.c:1748-1806) and, for the short alignments, the score of the MAIN DIAGONAL: diag[tid] = matches *
+// sc_mch + mismatches * sc_mis of an N-free qlen == tlen pair, GD_NEG_INF otherwise.  An alignment whose DP score equals it needs no
+// walk (ksw_backtrack_kernel): H(n, n) = sum over the diagonal of [H(k, k) - H(k - 1, k - 1)] with every term >= s(k, k), so equality
+// with the diagonal's sum makes the diagonal move a maximum in every cell of the diagonal, and the reference's priority order takes the
+// diagonal move first (SR/ksw2_extd2_sse.c:235-242): the walk from the last cell stays on the diagonal, the CIGAR is "<n>M".
 __global__ __launch_bounds__(64) void ksw_exact_match_kernel(const KswTask *__restrict__ tasks, int n,
                                                              const uint8_t *__restrict__ qseq,
                                                              const uint8_t *__restrict__ tseq,
                                                              int32_t *__restrict__ status, int32_t *__restrict__ score,
-                                                             int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar)
+                                                             int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar,
+                                                             int32_t *__restrict__ diag, int sc_mch, int sc_mis)
 {
 	const int tid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (tid >= n) return;
 	const KswTask T = tasks[tid];
-	int st = GD_ST_PENDING;
-	if (T.exact_score != GD_NEG_INF && T.qlen == T.tlen && T.qlen > 0) {
+	int st = GD_ST_PENDING, dg = GD_NEG_INF;
+	const bool want_exact = T.exact_score != GD_NEG_INF, want_diag = diag && T.kind == GD_KIND_WAVE16;
+	if ((want_exact || want_diag) && T.qlen == T.tlen && T.qlen > 0) {
 		const uint8_t *q = qseq + T.qoff, *t = tseq + T.toff;
 		// eight bases per load and compare (the windows sit at arbitrary byte offsets of the packed buffers: loads through memcpy, which the
-		// compiler may turn into unaligned 8-byte accesses where the target allows them), the tail byte by byte; a thread stops at its first
-		// difference
-		bool eq = true;
-		int k = 0;
-		for (; eq && k + 8 <= T.qlen; k += 8) {
+		// compiler may turn into unaligned 8-byte accesses where the target allows them), the tail byte by byte.  Without the diagonal's
+		// score to compute a thread stops at its first difference.
+		int n_mis = 0, k = 0;
+		uint64_t any = 0;
+		for (; (want_diag || !n_mis) && k + 8 <= T.qlen; k += 8) {
 			uint64_t a, b;
 			__builtin_memcpy(&a, q + k, 8), __builtin_memcpy(&b, t + k, 8);
-			eq = a == b;
+			const uint64_t x = a ^ b; // (nt4 codes: three bits per byte)
+			n_mis += __builtin_popcountll((x | x >> 1 | x >> 2) & 0x0101010101010101ull);
+			any |= a | b;
 		}
-		for (; eq && k < T.qlen; ++k) eq = q[k] == t[k];
-		if (eq) {
+		for (; (want_diag || !n_mis) && k < T.qlen; ++k) n_mis += q[k] != t[k], any |= (uint64_t)(q[k] | t[k]);
+		if (want_exact && !n_mis) {
 			st = GD_ST_EXACT;
 			score[tid] = T.exact_score;
 			n_cigar[tid] = 1;
 			if (T.cig_cap >= 1) cigar[T.cig_off] = (uint32_t)T.qlen << 4; // "<qlen>M", LR/map.c:1783-1784
 		}
+		if (want_diag && !(any & 0x0404040404040404ull)) dg = (T.qlen - n_mis) * sc_mch + n_mis * sc_mis; // (codes >= 4: N and its complements)
 	}
 	status[tid] = st;
+	if (diag) diag[tid] = dg;
 }
 
 // ksw_backtrack (SR/ksw2.h:131-163) of one alignment by ONE THREAD, from cell (i, j): the body of ksw_backtrack_kernel, and the tail of
@@ -145,7 +156,8 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
                                                            const int32_t *__restrict__ status,
                                                            int32_t *__restrict__ score, int32_t *__restrict__ n_cigar,
                                                            uint32_t *__restrict__ cigar, int spread, const int32_t *__restrict__ task_ids,
-                                                           const int32_t *__restrict__ start = nullptr /* (i0, j0) per task; default: the last cell */)
+                                                           const int32_t *__restrict__ start = nullptr /* (i0, j0) per task; default: the last cell */,
+                                                           const int32_t *__restrict__ diag = nullptr /* ksw_exact_match_kernel's diagonal scores */)
 {
 	// spread = 1: one alignment per WAVEFRONT (lane 0 walks, the other lanes idle).  Kept for experiments only: it measured 2x
 	// SLOWER than one walk per thread, whose 64 x 16 prefetched loads per wavefront hide the latency better.
@@ -164,6 +176,11 @@ __global__ __launch_bounds__(64) void ksw_backtrack_kernel(const KswTask *__rest
 		return;
 	}
 	const KswTask T = tasks[tid];
+	if (diag && !start && T.qlen == T.tlen && diag[tid] != GD_NEG_INF && score[tid] == diag[tid]) { // the walk would stay on the main diagonal (see ksw_exact_match_kernel)
+		n_cigar[tid] = 1;
+		if (T.cig_cap >= 1) cigar[T.cig_off] = (uint32_t)T.qlen << 4;
+		return;
+	}
 	gd_bt_thread_walk(T, tid, bt, n_cigar, cigar, start ? start[2 * tid] : T.tlen - 1, start ? start[2 * tid + 1] : T.qlen - 1);
 }
 

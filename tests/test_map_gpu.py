@@ -483,7 +483,8 @@ def test_degenerate_box_fails_its_read_not_the_batch(kind):
                                        ({"GDIET_POST_WAVE": "1"}, ["sr", "sr_var", "sr_edge", "hifi_edge"]),  # short ones through the wave-parallel form
                                        ({"GDIET_FUSE_BT_GROUPS": "1"}, ["sr", "sr_var", "sr_edge", "sr_rep"]),  # grouped DP kernels walking their own alignments back
                                        ({"GDIET_SR_BOXES": "host"}, ["sr", "sr_var", "sr_edge"]),  # ShortReads candidate geometry on host threads
-                                       ({"GDIET_SR_PIPE": "0"}, ["sr", "sr_var", "sr_edge", "sr_rep"])])  # short alignments on the grouped kernels only (no skewed pipelines)
+                                       ({"GDIET_SR_PIPE": "0"}, ["sr", "sr_var", "sr_edge", "sr_rep"]),  # short alignments on the grouped kernels only (no skewed pipelines)
+                                       ({"GDIET_DIAG_SHORTCUT": "0"}, ["sr", "sr_var", "sr_rep"])])  # every short alignment walked back, also those whose score equals the main diagonal's
 def test_golden_sam_under_the_other_post_kernel(env, kinds):
     """switches that select between two implementations of a stage (P1: one thread / one wavefront per alignment; the short-alignment
     DP kernels with / without their own walk; the ShortReads box stage on the device / the host; full-matrix short alignments as skewed pipelines / on the grouped kernels): each kind through the one it does
