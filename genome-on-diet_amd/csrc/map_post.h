@@ -109,6 +109,69 @@ GDP_HD void gdp_update_extra(uint32_t *cg, uint32_t *n_io, const uint8_t *qseq, 
 	int32_t blen = 0, mlen = 0;
 	uint32_t n_ambi_tot = 0;
 	const uint32_t n = *n_io;
+	if (!log_gap) {
+		// The short-read form (no logarithmic gap cost): every term of the running score is an integer, so the reference's double accumulator
+		// holds integers and int32 arithmetic gives the same values.  Eight bases per load; a group without an ambiguous base (codes 0..3
+		// on both sides: no bit 2 anywhere) scores mat[0] / mat[1] by equality, any other group goes through the table base by base.
+		int32_t si = 0, mxi = 0;
+		const int32_t mch = mat[0], mis = mat[1];
+		bool uniform = true; // (one match and one mismatch score among the four bases: what mm_set_opt builds; else everything through the table)
+		for (int i = 0; i < 4; ++i)
+			for (int j = 0; j < 4; ++j) uniform &= mat[i * 5 + j] == (i == j ? mch : mis);
+		for (uint32_t k = 0; k < n; ++k) {
+			const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
+			if (op == 0) {
+				int n_ambi = 0, n_diff = 0;
+				uint32_t l = 0;
+				for (; l + 8 <= len; l += 8) {
+					uint64_t a, b;
+					__builtin_memcpy(&a, qseq + qoff + l, 8), __builtin_memcpy(&b, tseq + toff + l, 8);
+					if (uniform && !((a | b) & 0x0404040404040404ull)) {
+						const uint64_t x = a ^ b;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+						for (int j = 0; j < 8; ++j) {
+							const int d = ((x >> (8 * j)) & 0xff) != 0;
+							n_diff += d;
+							si += d ? mis : mch;
+							if (si < 0) si = 0;
+							else mxi = mxi > si ? mxi : si;
+						}
+					} else
+						for (int j = 0; j < 8; ++j) {
+							const int cq = (int)((a >> (8 * j)) & 0xff), ct = (int)((b >> (8 * j)) & 0xff);
+							if (ct > 3 || cq > 3) ++n_ambi;
+							else if (ct != cq) ++n_diff;
+							si += (ct * 5 + cq < 25) ? (int32_t)mat[ct * 5 + cq] : 0;
+							if (si < 0) si = 0;
+							else mxi = mxi > si ? mxi : si;
+						}
+				}
+				for (; l < len; ++l) {
+					const int cq = qseq[qoff + l], ct = tseq[toff + l];
+					if (ct > 3 || cq > 3) ++n_ambi;
+					else if (ct != cq) ++n_diff;
+					si += (ct * 5 + cq < 25) ? (int32_t)mat[ct * 5 + cq] : 0;
+					if (si < 0) si = 0;
+					else mxi = mxi > si ? mxi : si;
+				}
+				blen += (int32_t)len - n_ambi, mlen += (int32_t)len - (n_ambi + n_diff), n_ambi_tot += (uint32_t)n_ambi;
+				toff += len, qoff += len;
+			} else if (op == 1 || op == 2) {
+				int n_ambi = 0;
+				for (uint32_t l = 0; l < len; ++l)
+					if ((op == 1 ? qseq[qoff + l] : tseq[toff + l]) > 3) ++n_ambi;
+				blen += (int32_t)len - n_ambi, n_ambi_tot += (uint32_t)n_ambi;
+				si -= (int32_t)(q + e);
+				if (si < 0) si = 0;
+				if (op == 1) qoff += len; else toff += len;
+			} else if (op == 3) toff += len;
+		}
+		out->qshift = qshift, out->tshift = tshift, out->mlen = mlen, out->blen = blen, out->n_ambi = n_ambi_tot;
+		out->dp_max = mxi; // ((int32_t)(mx + .499) of an integer-valued mx)
+		return;
+	}
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
 		if (op == 0) {
