@@ -187,6 +187,38 @@ def test_short_read_pipelines_match_oracle(gpu_ctx, pkg, oracle):
     assert n_exact >= 20
 
 
+def test_pipeline_runs_the_prefilter_empties(gpu_ctx, pkg, oracle):
+    """a run of one geometry in which the exact-match pre-filter answers EVERY alignment (the device-side compaction leaves its pipes
+    empty: wavefronts with nothing to do) beside a run it leaves alone, and a run with a single pending alignment"""
+    gdo, lib = oracle
+    rng = np.random.default_rng(99)
+    qs, ts, ws = [], [], []
+    for i in range(80):  # 90 x 90: all exact
+        t = rng.integers(0, 4, size=90, dtype=np.uint8)
+        qs.append(t.copy()), ts.append(t), ws.append(90)
+    for i in range(80):  # 110 x 110: one pending alignment among exact ones
+        t = rng.integers(0, 4, size=110, dtype=np.uint8)
+        q = t.copy()
+        if i == 37:
+            q[50] = (q[50] + 1) & 3
+            q = np.concatenate([q[:20], q[22:], rng.integers(0, 4, size=2, dtype=np.uint8)])
+        qs.append(np.ascontiguousarray(q)), ts.append(t), ws.append(110)
+    for i in range(60):  # 130 x 130: nothing exact
+        q, t = gdo.make_pair(rng, 170, 0.04, 0.01, 0.01)
+        qs.append(np.ascontiguousarray(q[:130])), ts.append(np.ascontiguousarray(t[:130])), ws.append(130)
+    ex = np.array([len(q) * 2 for q in qs], np.int32)
+    sc, cg = gpu_ctx.ksw_extd2_batch(qs, ts, ws, pkg.KswScore.from_preset("sr"), exact_score=ex)
+    assert gpu_ctx.last_kernel_mask() & 16
+    a, b, q_, e, q2, e2 = gdo.PRESETS["sr"]
+    mat = gdo.score_matrix(a, b)
+    for i in range(len(qs)):
+        if np.array_equal(qs[i], ts[i]):
+            assert sc[i] == ex[i] and list(cg[i]) == [len(qs[i]) << 4], i
+            continue
+        o = gdo.oracle_extd2(lib, qs[i], ts[i], mat, q_, e, q2, e2, ws[i])
+        assert sc[i] == o["score"] and np.array_equal(cg[i], o["cigar"]), (i, len(qs[i]), sc[i], o["score"])
+
+
 def test_pipelines_and_grouped_kernels_agree_at_scale():
     """120 000 short-read-shaped pairs (a short-read batch's size per GPU wavefront slot; a quarter exact matches, which the device-side
     compaction drops from the pipes) through the skewed pipelines and, in a second process with GDIET_SR_PIPE=0, through the grouped
