@@ -2,7 +2,8 @@
 """Whole-path throughput of the other two canonical configurations (BASELINE configs[2] ShortReads, configs[4] ONT) on one GPU.
 Not the headline bench (bench.py = configs[3]); same structure, smaller synthetic reference by default.
 
-    python tools/bench_variant.py --kind sr  [--batch 262144] [--ref-mbp 400] [--steps 5]
+    python tools/bench_variant.py --kind sr  [--batch 262144] [--inflight 8] [--ref-mbp 3088] [--steps 256]
+      (a ShortReads batch is a chain of short kernels and host stages: eight batches in flight keep the GPU busy, 32.8 M reads/s; four: 22.6 M)
     python tools/bench_variant.py --kind ont [--batch 12288] [--inflight 3] [--ref-mbp 3088] [--steps 4]
       (12288 reads per batch = three rounds of the 4096 resident wavefronts of the checkpointed wide-band kernel (96-block ring, 4 per SIMD): the long tail of the
       read-length distribution -- a 150 kbp read runs three times as long as the median one -- is then hidden behind the refill)
