@@ -30,17 +30,24 @@ static inline __host__ __device__ uint32_t gd_bt_decode(uint32_t b)
 	return (4u - (b & 7u)) | ((nb >> 4) & 0x08u) | ((nb >> 2) & 0x10u) | (nb & 0x20u) | ((nb << 2) & 0x40u);
 }
 
-// Pre-filter (exact_match_sse, LR/map.c:1748-1806) and, for the short alignments, the score of the MAIN DIAGONAL: diag[tid] = matches *
-// sc_mch + mismatches * sc_mis of an N-free qlen == tlen pair, GD_NEG_INF otherwise.  An alignment whose DP score equals it needs no
-// walk (ksw_backtrack_kernel): H(n, n) = sum over the diagonal of [H(k, k) - H(k - 1, k - 1)] with every term >= s(k, k), so equality
-// with the diagonal's sum makes the diagonal move a maximum in every cell of the diagonal, and the reference's priority order takes the
-// diagonal move first (SR/ksw2_extd2_sse.c:235-242): the walk from the last cell stays on the diagonal, the CIGAR is "<n>M".
+// Pre-filter (exact_match_sse, LR/map.c:1748-1806), widened by what can be PROVEN about the DP without running it.  For an N-free pair
+// with qlen == tlen = n and m mismatches the main diagonal scores D = (n - m) a - m b (a = sc_mch, b = -sc_mis).
+//   (1) No DP.  A path from corner to corner that is not the diagonal holds at least one insertion run and one deletion run of equal total
+//       length G >= 1; every run costs at least min(q + e, q2 + e2) = q + e (normalised so), and only n - G pairs are left to score at most a
+//       each: such a path scores at most (n - 1) a - 2 (q + e).  If m (a + b) < a + 2 (q + e) the diagonal beats every other path, so
+//       ksw_extd2 / ksw_extz2 return score D and, by (2), the CIGAR "<n>M": the alignment is answered here (status EXACT) exactly as
+//       the reference's own pre-filter answers m == 0.  With the short-read scoring (a 2, b 8, q 12, e 2): m <= 2 -- 81 % of 150-base
+//       reads at 1 % substitutions.  `gap_thr` = a + 2 (q + e); 0 switches (1) off.
+//   (2) No walk.  diag[tid] = D for the alignments that do go through the DP (GD_NEG_INF where there is an N or qlen != tlen): if the DP
+//       score equals it, H(n, n) = sum over the diagonal of [H(k, k) - H(k - 1, k - 1)] with every term >= s(k, k), so equality makes the
+//       diagonal move a maximum in every cell of the diagonal, and the reference's priority order takes the diagonal move first
+//       (SR/ksw2_extd2_sse.c:235-242): the walk from the last cell stays on the diagonal (ksw_backtrack_kernel writes "<n>M" unwalked).
 __global__ __launch_bounds__(64) void ksw_exact_match_kernel(const KswTask *__restrict__ tasks, int n,
                                                              const uint8_t *__restrict__ qseq,
                                                              const uint8_t *__restrict__ tseq,
                                                              int32_t *__restrict__ status, int32_t *__restrict__ score,
                                                              int32_t *__restrict__ n_cigar, uint32_t *__restrict__ cigar,
-                                                             int32_t *__restrict__ diag, int sc_mch, int sc_mis)
+                                                             int32_t *__restrict__ diag, int sc_mch, int sc_mis, int gap_thr)
 {
 	const int tid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (tid >= n) return;
@@ -68,7 +75,15 @@ __global__ __launch_bounds__(64) void ksw_exact_match_kernel(const KswTask *__re
 			n_cigar[tid] = 1;
 			if (T.cig_cap >= 1) cigar[T.cig_off] = (uint32_t)T.qlen << 4; // "<qlen>M", LR/map.c:1783-1784
 		}
-		if (want_diag && !(any & 0x0404040404040404ull)) dg = (T.qlen - n_mis) * sc_mch + n_mis * sc_mis; // (codes >= 4: N and its complements)
+		if (want_diag && !(any & 0x0404040404040404ull)) { // (codes >= 4: N and its complements)
+			dg = (T.qlen - n_mis) * sc_mch + n_mis * sc_mis;
+			if (st == GD_ST_PENDING && n_mis * (sc_mch - sc_mis) < gap_thr) { // (1): no other path can reach the diagonal's score
+				st = GD_ST_EXACT;
+				score[tid] = dg;
+				n_cigar[tid] = 1;
+				if (T.cig_cap >= 1) cigar[T.cig_off] = (uint32_t)T.qlen << 4;
+			}
+		}
 	}
 	status[tid] = st;
 	if (diag) diag[tid] = dg;

@@ -221,19 +221,20 @@ def test_pipeline_runs_the_prefilter_empties(gpu_ctx, pkg, oracle):
 
 def test_pipelines_and_grouped_kernels_agree_at_scale():
     """120 000 short-read-shaped pairs (a short-read batch's size per GPU wavefront slot; a quarter exact matches, which the device-side
-    compaction drops from the pipes) through the skewed pipelines and, in a second process with GDIET_SR_PIPE=0, through the grouped
-    kernels: one digest over every score and CIGAR (tests/pipe_digest_check.py).  The grouped kernels are pinned to the oracle and the
+    compaction drops from the pipes) through the skewed pipelines, in a second process with GDIET_SR_PIPE=0 through the grouped
+    kernels, and in a third with GDIET_DIAG_SHORTCUT=0 (no alignment answered from its main diagonal's score: every one through DP and walk):
+    one digest over every score and CIGAR (tests/pipe_digest_check.py).  The grouped kernels are pinned to the oracle and the
     reference's goldens by the tests around this one; this is the same comparison at a size the oracle would need minutes for."""
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pipe_digest_check.py")
     outs = []
-    for env in ({}, {"GDIET_SR_PIPE": "0"}):
+    for env in ({}, {"GDIET_SR_PIPE": "0"}, {"GDIET_DIAG_SHORTCUT": "0"}):  # (the last: pipelines, but every alignment through the DP and the walk)
         r = subprocess.run([sys.executable, script], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
         assert r.returncode == 0 and "digest" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
         outs.append(r.stdout.strip().split("\n")[-1].split())
-    assert int(outs[0][1]) & 16 and not int(outs[1][1]) & 16, outs  # the first run used the pipelines, the second did not
-    assert outs[0][-1] == outs[1][-1], outs
+    assert int(outs[0][1]) & 16 and not int(outs[1][1]) & 16 and int(outs[2][1]) & 16, outs  # the second run did without the pipelines
+    assert outs[0][-1] == outs[1][-1] == outs[2][-1], outs
 
 
 def test_short_read_group_widths_match_oracle(gpu_ctx, pkg, oracle):

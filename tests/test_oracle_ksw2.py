@@ -98,3 +98,56 @@ def test_extz2_equals_extd2_with_equal_gap_models(oracle):
         a, b, go, ge, _, _ = gdo.PRESETS[c["preset"]]
         d = gdo.oracle_extd2(lib, c["q"], c["t"], gdo.score_matrix(a, b), go, ge, go, ge, c["w"])
         assert d["score"] == c["score"] and np.array_equal(d["cigar"], c["cigar"])
+
+
+def _diag_cases(rng, n_cases, a, b, thr):
+    """N-free pairs of equal length whose only differences are m substitutions with m (a + b) < thr: random, tandem-repeat and two-letter
+    targets (where a gapped path re-aligns the most), scattered and adjacent mismatches"""
+    mmax = (thr - 1) // (a + b)
+    for it in range(n_cases):
+        n = int(rng.integers(17, 260))
+        kind = it % 4
+        if kind == 0:
+            t = rng.integers(0, 4, size=n, dtype=np.uint8)
+        elif kind == 1:
+            t = np.resize(rng.integers(0, 4, size=int(rng.integers(1, 7)), dtype=np.uint8), n).astype(np.uint8)
+        elif kind == 2:
+            t = rng.integers(0, 2, size=n, dtype=np.uint8)
+        else:
+            t = np.resize(rng.integers(0, 4, size=int(rng.integers(2, 9)), dtype=np.uint8), n).astype(np.uint8)
+            t[rng.integers(0, n, size=3)] = rng.integers(0, 4, size=3)
+        m = int(rng.integers(0, mmax + 1))
+        q = t.copy()
+        pos = [int(x) for x in rng.choice(n, size=m, replace=False)] if m else []
+        if it % 3 == 0 and m >= 2:
+            pos[1] = min(n - 1, pos[0] + 1)
+        for p in set(pos):
+            q[p] = (q[p] + 1 + rng.integers(0, 3)) & 3
+        mm = int((q != t).sum())
+        if mm * (a + b) < thr:
+            yield q, t, mm
+
+
+def test_few_mismatches_mean_the_main_diagonal(oracle):
+    """what the library's widened pre-filter rests on (ksw_exact_match_kernel, csrc/ksw_backtrack.hip.h): an N-free pair of equal length
+    with m substitutions and m (a + b) < a + 2 (q + e) aligns along its main diagonal -- score (n - m) a - m b, CIGAR "<n>M" -- because any
+    other corner-to-corner path pays two gap opens and scores one pair less.  Checked on the oracle for the three presets, wide and
+    narrow bands, and on the reference's own ksw_extd2_sse where oracle/_ref is built"""
+    gdo, lib = oracle
+    ref = gdo.load_ref() if gdo.have_ref() else None
+    rng = np.random.default_rng(2025)
+    n = 0
+    for name, (a, b, go, ge, go2, ge2) in gdo.PRESETS.items():
+        if go2 + ge2 < go + ge:
+            go, ge, go2, ge2 = go2, ge2, go, ge
+        mat = gdo.score_matrix(a, b)
+        for q, t, mm in _diag_cases(rng, 700, a, b, a + 2 * (go + ge)):
+            ln = len(q)
+            for w in (ln, ln // 3 + 20):
+                o = gdo.oracle_extd2(lib, q, t, mat, go, ge, go2, ge2, w)
+                assert o["score"] == (ln - mm) * a - mm * b and list(o["cigar"]) == [ln << 4], (name, ln, mm, w)
+                if ref is not None and n % 5 == 0:
+                    r = gdo.ref_extd2(ref, q, t, mat, go, ge, go2, ge2, w)
+                    assert r["score"] == o["score"] and np.array_equal(r["cigar"], o["cigar"]), (name, ln, mm, w)
+                n += 1
+    assert n > 3000
