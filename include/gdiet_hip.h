@@ -75,6 +75,11 @@ int gdiet_hip_last_kernel_mask(const gdiet_ctx *ctx);
  *   n_cigar[i] = ez.n_cigar; cigar ops (BAM encoding len<<4|op, op 0=M 1=I 2=D) at cigar[cigar_off[i] ..)
  *   the caller provides cigar_off[n+1]; capacity of alignment i is cigar_off[i+1]-cigar_off[i]
  *   (qlen+tlen always suffices).
+ * How a result is obtained is the library's business, what it is is the reference's: short alignments (a target of at most 256 bases) whose
+ * result can be proven without the DP -- an N-free pair of equal length with so few mismatches that no gapped path can reach the main
+ * diagonal's score: m (a + b) < a + 2 (q + e) -- are answered by the pre-filter kernel with exactly what ksw_extd2 + ksw_backtrack return
+ * for them (tests/test_oracle_ksw2.py pins the property on the reference's own ksw_extd2_sse).  GDIET_DIAG_SHORTCUT=0 in
+ * the environment sends every alignment through the DP kernels and the walk.
  */
 int gdiet_hip_ksw_extd2_batch(gdiet_ctx *ctx, int n,
                               const uint8_t *qseq, const int64_t *qoff,
