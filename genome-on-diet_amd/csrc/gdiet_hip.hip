@@ -609,6 +609,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	// run fills the GPU's wavefront slots once.  GDIET_SR_PIPE=0 keeps the grouped kernels; GDIET_PIPE_NP forces np.
 	const bool use_pipe = gd_use_pipe;
 	static const int pipe_np_forced = getenv("GDIET_PIPE_NP") ? atoi(getenv("GDIET_PIPE_NP")) : 0;
+	static const int pipe_np_min = getenv("GDIET_PIPE_NP_MIN") ? std::max(1, atoi(getenv("GDIET_PIPE_NP_MIN"))) : 8; // see pipe_compact_kernel
 	std::vector<int32_t> pipe_ids;
 	ctx->h_pipes.clear(), ctx->h_pipe_runs.clear();
 	{
@@ -637,7 +638,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 					const size_t n_waves = (m + geo.NG * np - 1) / (geo.NG * np);
 					PipeRun R;
 					memset(&R, 0, sizeof(R));
-					R.src_off = (int32_t)pipe_ids.size(), R.dst_off = R.src_off, R.m = (int32_t)m, R.wave_off = (int32_t)ctx->h_pipes.size(), R.n_waves = (int32_t)n_waves, R.ng = geo.NG;
+					R.src_off = (int32_t)pipe_ids.size(), R.dst_off = R.src_off, R.m = (int32_t)m, R.wave_off = (int32_t)ctx->h_pipes.size(), R.n_waves = (int32_t)n_waves, R.ng = geo.NG, R.np_min = (int32_t)std::max<size_t>(1, std::min<size_t>(np, (size_t)pipe_np_min));
 					for (size_t k = i; k < j; ++k) pipe_ids.push_back(v[k]);
 					PipeWave W; // (id_off, cnt, np: pipe_compact_kernel, once the pre-filter has answered)
 					memset(&W, 0, sizeof(W));

@@ -19,7 +19,7 @@ struct PipeWave { int32_t id_off, qlen, tlen, np, row_bytes, cnt, pad[2]; };
 // which of them the exact-match pre-filter will answer (22 % of a 1 %-error short-read batch): pipe_compact_kernel, between the
 // pre-filter and the DP, keeps the ids that are still pending and deals them out to the run's wavefronts in equal shares -- a slot of a
 // pipe that holds an answered alignment would cost its qlen + 15 steps all the same.
-struct PipeRun { int32_t src_off, m, dst_off, wave_off, n_waves, ng, count, done; }; // count / done: zero when uploaded, the kernel's counters
+struct PipeRun { int32_t src_off, m, dst_off, wave_off, n_waves, ng, count, done, np_min, pad[3]; }; // count / done: zero when uploaded, the kernel's counters
 
 // Blocks of GDP_COMPACT_THREADS x GDP_COMPACT_ITEMS ids each, grid (chunks of the longest run, runs).  The order of a run's alignments
 // does not matter (every alignment is computed on its own), so a wavefront reserves room for its pending ids with one atomic add on the
@@ -62,9 +62,14 @@ __global__ __launch_bounds__(GDP_COMPACT_THREADS) void pipe_compact_kernel(PipeR
 	__syncthreads();
 	if (!s_last) return;
 	__threadfence();
-	const int total = atomicAdd(&R.count, 0), q = total / R.n_waves, rem = total % R.n_waves;
+	// (what the pre-filter left may be a fraction of the run -- a fifth of a 1 %-error short-read batch: pipes of np_min alignments per group
+	// at least, on as many of the run's wavefronts as that takes; the others find cnt == 0 and leave at once)
+	const int total = atomicAdd(&R.count, 0);
+	int n_act = (total + R.ng * R.np_min - 1) / (R.ng * R.np_min);
+	n_act = n_act < 1 ? 1 : n_act > R.n_waves ? R.n_waves : n_act;
+	const int q = total / n_act, rem = total % n_act;
 	for (int w = threadIdx.x; w < R.n_waves; w += GDP_COMPACT_THREADS) {
-		const int cnt = q + (w < rem), a0 = w * q + (w < rem ? w : rem);
+		const int cnt = w < n_act ? q + (w < rem) : 0, a0 = w < n_act ? w * q + (w < rem ? w : rem) : 0;
 		PipeWave &W = pipes[R.wave_off + w];
 		W.id_off = R.dst_off + a0, W.cnt = cnt, W.np = (cnt + R.ng - 1) / R.ng;
 	}
@@ -88,6 +93,7 @@ __global__ __launch_bounds__(64 * GDP_BLOCK_WAVES) __attribute__((amdgpu_waves_p
 	if (pw >= n_pipes) return;
 	uint8_t *const lds = lds_all[wv];
 	const int id_off = __builtin_amdgcn_readfirstlane(pipes[pw].id_off), np = __builtin_amdgcn_readfirstlane(pipes[pw].np), cnt = __builtin_amdgcn_readfirstlane(pipes[pw].cnt);
+	if (np <= 0) return; // (a wavefront the compaction left without work; no barrier binds the wavefronts of a workgroup)
 	const int row_bytes = __builtin_amdgcn_readfirstlane(pipes[pw].row_bytes);
 	const PipeGeo Gm = gd_pipe_geo(__builtin_amdgcn_readfirstlane(pipes[pw].qlen), __builtin_amdgcn_readfirstlane(pipes[pw].tlen));
 	const int G = Gm.G, NG = Gm.NG, P = Gm.P, qlen = Gm.qlen, tlen = Gm.tlen;
