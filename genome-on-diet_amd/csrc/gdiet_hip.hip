@@ -734,7 +734,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		d_diag = (int32_t *)ctx->diag.p;
 	}
 	hipLaunchKernelGGL(ksw_exact_match_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_tasks, n, d_qseq, d_tseq,
-	                   d_status, d_score, d_n_cigar, d_cigar, d_diag, (int)K.sc_mch, (int)K.sc_mis, d_diag && K.sc_mis <= K.sc_mch && K.q + K.e > 0 ? (int)(K.sc_mch + 2 * (K.q + K.e)) : 0);
+	                   d_status, d_score, d_n_cigar, d_cigar, d_diag, (int)K.sc_mch, (int)K.sc_mis, d_diag && K.sc_mis <= K.sc_mch && K.q + K.e > 0 ? (int)(K.sc_mch + 2 * (K.q + K.e)) + 1 : 0);
 	// Head / tail split of a big 64-lane launch.  The grid is sorted longest-first, so the first `wave_slots` alignments start at
 	// once and the rest fill in as slots free up -- it is the latter that finish last.  Launched as two kernels (head on the
 	// caller's stream, tail on a second one), the head's backtrack runs while the tail is still in the DP, and only the tail's

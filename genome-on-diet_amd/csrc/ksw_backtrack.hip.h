@@ -34,10 +34,11 @@ static inline __host__ __device__ uint32_t gd_bt_decode(uint32_t b)
 // with qlen == tlen = n and m mismatches the main diagonal scores D = (n - m) a - m b (a = sc_mch, b = -sc_mis).
 //   (1) No DP.  A path from corner to corner that is not the diagonal holds at least one insertion run and one deletion run of equal total
 //       length G >= 1; every run costs at least min(q + e, q2 + e2) = q + e (normalised so), and only n - G pairs are left to score at most a
-//       each: such a path scores at most (n - 1) a - 2 (q + e).  If m (a + b) < a + 2 (q + e) the diagonal beats every other path, so
-//       ksw_extd2 / ksw_extz2 return score D and, by (2), the CIGAR "<n>M": the alignment is answered here (status EXACT) exactly as
-//       the reference's own pre-filter answers m == 0.  With the short-read scoring (a 2, b 8, q 12, e 2): m <= 2 -- 81 % of 150-base
-//       reads at 1 % substitutions.  `gap_thr` = a + 2 (q + e); 0 switches (1) off.
+//       each: such a path scores at most (n - 1) a - 2 (q + e).  If m (a + b) <= a + 2 (q + e) no other path beats the diagonal, so
+//       ksw_extd2 / ksw_extz2 return score D and, by (2) -- which only needs the score to EQUAL D, so a tie is fine --, the CIGAR "<n>M":
+//       the alignment is answered here (status EXACT) exactly as the reference's own pre-filter answers m == 0.  With the short-read
+//       scoring (a 2, b 8, q 12, e 2): m <= 3 -- 93 % of 150-base reads at 1 % substitutions.  `gap_thr` = a + 2 (q + e) + 1 (the
+//       comparison below is strict); 0 switches (1) off.
 //   (2) No walk.  diag[tid] = D for the alignments that do go through the DP (GD_NEG_INF where there is an N or qlen != tlen): if the DP
 //       score equals it, H(n, n) = sum over the diagonal of [H(k, k) - H(k - 1, k - 1)] with every term >= s(k, k), so equality makes the
 //       diagonal move a maximum in every cell of the diagonal, and the reference's priority order takes the diagonal move first

@@ -77,7 +77,7 @@ int gdiet_hip_last_kernel_mask(const gdiet_ctx *ctx);
  *   (qlen+tlen always suffices).
  * How a result is obtained is the library's business, what it is is the reference's: short alignments (a target of at most 256 bases) whose
  * result can be proven without the DP -- an N-free pair of equal length with so few mismatches that no gapped path can reach the main
- * diagonal's score: m (a + b) < a + 2 (q + e) -- are answered by the pre-filter kernel with exactly what ksw_extd2 + ksw_backtrack return
+ * diagonal's score: m (a + b) <= a + 2 (q + e) -- are answered by the pre-filter kernel with exactly what ksw_extd2 + ksw_backtrack return
  * for them (tests/test_oracle_ksw2.py pins the property on the reference's own ksw_extd2_sse).  GDIET_DIAG_SHORTCUT=0 in
  * the environment sends every alignment through the DP kernels and the walk.
  */

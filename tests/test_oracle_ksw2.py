@@ -101,9 +101,9 @@ def test_extz2_equals_extd2_with_equal_gap_models(oracle):
 
 
 def _diag_cases(rng, n_cases, a, b, thr):
-    """N-free pairs of equal length whose only differences are m substitutions with m (a + b) < thr: random, tandem-repeat and two-letter
+    """N-free pairs of equal length whose only differences are m substitutions with m (a + b) <= thr: random, tandem-repeat and two-letter
     targets (where a gapped path re-aligns the most), scattered and adjacent mismatches"""
-    mmax = (thr - 1) // (a + b)
+    mmax = thr // (a + b)
     for it in range(n_cases):
         n = int(rng.integers(17, 260))
         kind = it % 4
@@ -124,14 +124,15 @@ def _diag_cases(rng, n_cases, a, b, thr):
         for p in set(pos):
             q[p] = (q[p] + 1 + rng.integers(0, 3)) & 3
         mm = int((q != t).sum())
-        if mm * (a + b) < thr:
+        if mm * (a + b) <= thr:
             yield q, t, mm
 
 
 def test_few_mismatches_mean_the_main_diagonal(oracle):
     """what the library's widened pre-filter rests on (ksw_exact_match_kernel, csrc/ksw_backtrack.hip.h): an N-free pair of equal length
-    with m substitutions and m (a + b) < a + 2 (q + e) aligns along its main diagonal -- score (n - m) a - m b, CIGAR "<n>M" -- because any
-    other corner-to-corner path pays two gap opens and scores one pair less.  Checked on the oracle for the three presets, wide and
+    with m substitutions and m (a + b) <= a + 2 (q + e) aligns along its main diagonal -- score (n - m) a - m b, CIGAR "<n>M" -- because any
+    other corner-to-corner path pays two gap opens and scores one pair less (at equality a gapped path may tie; the backtrack's priority
+    order still walks the diagonal).  Checked on the oracle for the three presets, wide and
     narrow bands, and on the reference's own ksw_extd2_sse where oracle/_ref is built"""
     gdo, lib = oracle
     ref = gdo.load_ref() if gdo.have_ref() else None
