@@ -552,7 +552,6 @@ static inline void gd_sr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 	const int g = O.a, bb = O.b < 0 ? O.b : -O.b;
 	int8_t mat[25];
 	for (int i = 0; i < 25; ++i) mat[i] = (i / 5 == 4 || i % 5 == 4) ? 0 : (i / 5 == i % 5 ? (int8_t)g : (int8_t)bb);
-	static thread_local std::vector<uint8_t> tseq; // (scratch kept per thread: this runs once per read, millions of times per second)
 	out.reserve(C.size());
 	for (size_t i = 0; i < C.size(); ++i) {
 		const GdCand &c = C[i];
@@ -566,6 +565,7 @@ static inline void gd_sr_finish(std::vector<GdCand> &C, const std::vector<GdDpRe
 		r.dp_score = dp[i].score;
 		if (post) gd_apply_post(r, post[i]);
 		else {
+			static thread_local std::vector<uint8_t> tseq; // (scratch kept per thread; only P1 on the host comes here)
 			tseq.assign((size_t)c.tlen + 16, 0);
 			gd_getseq(R, c.target_id, c.target_start, c.target_end + 1, tseq.data());
 			const uint8_t *qseq = (c.v.str ? enc_rev : enc_for) + c.qseq_off;

@@ -272,10 +272,14 @@ struct GdRegHead { uint32_t magic, head; uint64_t pad; };
 static const uint32_t GD_REG_MAGIC = 0x67645247u;
 static const size_t GD_REG_SLAB = 1 << 20;
 
-static void *gd_reg_slab_take(uint64_t call_id, size_t bytes, bool &head)
+struct GdRegCursor { uint64_t call = 0; char *p = nullptr; size_t left = 0; };
+static GdRegCursor &gd_reg_cursor() // (this thread's: fetched once per chunk of reads -- a thread_local of a shared library costs a call per access)
 {
-	struct Cursor { uint64_t call = 0; char *p = nullptr; size_t left = 0; };
-	static thread_local Cursor C;
+	static thread_local GdRegCursor C;
+	return C;
+}
+static void *gd_reg_slab_take(GdRegCursor &C, uint64_t call_id, size_t bytes, bool &head)
+{
 	head = false;
 	if (C.call != call_id || C.left < bytes) { // what is left of the previous slab stays with its records
 		const size_t sz = std::max(bytes, GD_REG_SLAB);
@@ -915,37 +919,51 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	static std::atomic<uint64_t> call_counter{0};
 	const uint64_t call_id = ++call_counter; // names the slabs of this call (GdRegSlab)
 	std::atomic<int> no_mem{0};
-	gd_parallel_for(ctx, ctx->lane_threads, n, [&](int i) {
-		n_regs[i] = 0, regs[i] = nullptr;
-		const size_t nc = (size_t)ccount[i];
-		if (!nc) return;
+	// (chunks of reads: the worker's scratch -- thread_local vectors, each access a call in a shared library -- is looked up once per chunk,
+	// not six times per read; a short-read batch runs this body a quarter of a million times)
+	const int post_chunk = 256, n_post_chunks = (n + post_chunk - 1) / post_chunk;
+	gd_parallel_for(ctx, ctx->lane_threads, n_post_chunks, [&](int ch) {
 		// scratch of the worker thread, reused from read to read (the workers are persistent)
-		static thread_local std::vector<GdCand> C;
-		static thread_local std::vector<uint8_t> rev;
-		static thread_local std::vector<GdDpResult> dp;
-		C.assign(nc, GdCand()); // the records grow CIGARs: this thread's copy
-		for (size_t j = 0; j < nc; ++j) gd_cand_unbox(cflat[(size_t)cfirst[i] + j], C[j]);
-		const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
-		const uint8_t *enc = B.enc + B.roff[i];
-		// the reverse-complemented read: for P1 on the host, else only where a reverse-strand candidate may be concatenated (P2)
-		bool need_rev = false;
-		for (auto &c : C) need_rev |= c.v.str != 0 && (!post_dev || c.next >= 0);
-		if (need_rev) { rev.resize(rl); for (uint32_t j = 0; j < rl; ++j) rev[rl - 1 - j] = enc[j] ^ 3; }
-		dp.resize(nc);
-		for (size_t j = 0; j < nc; ++j) {
-			const int b = box_first[i] + (int)j;
-			dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig + poff[b];
+		static thread_local std::vector<GdCand> C_tl;
+		static thread_local std::vector<uint8_t> rev_tl;
+		static thread_local std::vector<GdDpResult> dp_tl;
+		static thread_local std::vector<GdReg> out_tl;
+		std::vector<GdCand> &C = C_tl;
+		std::vector<uint8_t> &rev = rev_tl;
+		std::vector<GdDpResult> &dp = dp_tl;
+		std::vector<GdReg> &out = out_tl;
+		GdRegCursor &cursor = gd_reg_cursor();
+		const int i_end = std::min(n, (ch + 1) * post_chunk);
+		for (int i = ch * post_chunk; i < i_end; ++i) {
+			n_regs[i] = 0, regs[i] = nullptr;
+			const size_t nc = (size_t)ccount[i];
+			if (!nc) continue;
+			// the records grow CIGARs: this thread's copy.  (ShortReads: gd_sr_finish reads the box fields only, which gd_cand_unbox sets all of --
+			// the elements are reused as they are; LongReads: fresh records, concatenate_cigars works inside them)
+			if (is_sr) C.resize(nc);
+			else C.assign(nc, GdCand());
+			for (size_t j = 0; j < nc; ++j) gd_cand_unbox(cflat[(size_t)cfirst[i] + j], C[j]);
+			const uint32_t rl = (uint32_t)(B.roff[i + 1] - B.roff[i]);
+			const uint8_t *enc = B.enc + B.roff[i];
+			// the reverse-complemented read: for P1 on the host, else only where a reverse-strand candidate may be concatenated (P2)
+			bool need_rev = false;
+			for (auto &c : C) need_rev |= c.v.str != 0 && (!post_dev || c.next >= 0);
+			if (need_rev) { rev.resize(rl); for (uint32_t j = 0; j < rl; ++j) rev[rl - 1 - j] = enc[j] ^ 3; }
+			dp.resize(nc);
+			for (size_t j = 0; j < nc; ++j) {
+				const int b = box_first[i] + (int)j;
+				dp[j].score = h_score[b], dp[j].n_cigar = h_ncig[b], dp[j].cigar = h_cig + poff[b];
+			}
+			out.clear();
+			const GdPostOut *pre = post_dev ? h_post + box_first[i] : nullptr;
+			if (is_sr) gd_sr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out, pre);
+			else gd_lr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out, nullptr, pre);
+			if (out.empty()) continue;
+			bool head = false;
+			void *at = gd_reg_slab_take(cursor, call_id, gd_regs_bytes(out), head);
+			if (!at) { no_mem.store(1); continue; }
+			gd_regs_fill(out, at, head, &n_regs[i], &regs[i]);
 		}
-		static thread_local std::vector<GdReg> out;
-		out.clear();
-		const GdPostOut *pre = post_dev ? h_post + box_first[i] : nullptr;
-		if (is_sr) gd_sr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out, pre);
-		else gd_lr_finish(C, dp, O, R, rl, enc, need_rev ? rev.data() : enc, out, nullptr, pre);
-		if (out.empty()) return;
-		bool head = false;
-		void *at = gd_reg_slab_take(call_id, gd_regs_bytes(out), head);
-		if (!at) { no_mem.store(1); return; }
-		gd_regs_fill(out, at, head, &n_regs[i], &regs[i]);
 	});
 	if (no_mem.load()) { gdiet_hip_free_regs(n, n_regs, regs); ctx->err = "out of host memory for the records"; return GDIET_E_NOMEM; }
 	ctx->stage_s[4] += gd_now() - t0;
