@@ -920,8 +920,8 @@ static int gd_map_range(gdiet_ctx *ctx, const gdiet_index *ix, const GdMapOpt &O
 	const uint64_t call_id = ++call_counter; // names the slabs of this call (GdRegSlab)
 	std::atomic<int> no_mem{0};
 	// (chunks of reads: the worker's scratch -- thread_local vectors, each access a call in a shared library -- is looked up once per chunk,
-	// not six times per read; a short-read batch runs this body a quarter of a million times)
-	const int post_chunk = 256, n_post_chunks = (n + post_chunk - 1) / post_chunk;
+	// not six times per read; a short-read batch runs this body a quarter of a million times: chunks of 256 there)
+	const int post_chunk = std::max(16, std::min(256, n / std::max(1, 8 * ctx->lane_threads))), n_post_chunks = (n + post_chunk - 1) / post_chunk; // (a long-read batch of 5 120 reads still spreads over every thread)
 	gd_parallel_for(ctx, ctx->lane_threads, n_post_chunks, [&](int ch) {
 		// scratch of the worker thread, reused from read to read (the workers are persistent)
 		static thread_local std::vector<GdCand> C_tl;
