@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <functional>
 #include <atomic>
+#include <chrono>
 #include <deque>
 #include <unordered_map>
 #include <memory>
@@ -486,6 +487,17 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	const int64_t *h_cig = h_cigar_off;
 	const int32_t *h_ex = h_exact_score;
 
+	// GDIET_TRACE_STAGES: where the planner's time goes (one line per call on stderr)
+	static const bool plan_trace = getenv("GDIET_TRACE_STAGES") != nullptr;
+	std::string plan_s;
+	double plan_t = plan_trace ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
+	auto plan_mark = [&](const char *what) {
+		if (!plan_trace) return;
+		const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+		char b[64];
+		snprintf(b, sizeof b, " %s %.2f", what, 1e3 * (t - plan_t));
+		plan_s += b, plan_t = t;
+	};
 	if ((rc = gd_host_grow(ctx, ctx->h_tasks, sizeof(KswTask) * (size_t)n))) return rc;
 	KswTask *h_tasks = (KswTask *)ctx->h_tasks.p;
 	const bool wave_scoring_ok = gd_wave_scoring_ok(K);
@@ -498,50 +510,72 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	// of the band (~1 000 steps for a 15 kbp alignment: 4-5 ms for the 9 400 alignments of a HiFi batch on one thread -- time that sat
 	// between the gather kernel and the DP kernel whenever a batch was not ready early).  Slices with a memo each: a short-read
 	// batch repeats a few geometries.
+	// (the same pass fills every other field of the descriptor, checks it, adds up the roofline accounting and lists the alignments by
+	// kind -- per slice, joined in slice order afterwards: done by one thread this was 3-5 ms per 262 144 short alignments, most of a
+	// short-read batch's planning)
+	struct PlanSlice { uint64_t cells = 0, alg = 0; int max_cap = 0, err = 0; uint32_t mask = 0; std::vector<int32_t> ids[4]; };
+	const int n_sl = std::max(1, std::min(64, n / 256));
+	std::vector<PlanSlice> slices((size_t)n_sl);
 	{
-		const int n_sl = std::max(1, std::min(64, n / 256));
 		gd_parallel_for(ctx, ctx->lane_threads, n_sl, [&](int sl) {
 			struct { int qlen = -1, tlen = -1, w = 0; int32_t kind = 0, row_bytes = 0; } memo;
+			PlanSlice &S = slices[sl];
 			const int i0 = (int)((int64_t)n * sl / n_sl), i1 = (int)((int64_t)n * (sl + 1) / n_sl);
+			for (int k = 0; k < 4; ++k) S.ids[k].reserve((size_t)(i1 - i0));
 			for (int i = i0; i < i1; ++i) {
 				KswTask &T = h_tasks[i];
 				T.qlen = (int)(h_qoff[i + 1] - h_qoff[i]), T.tlen = (int)(h_toff[i + 1] - h_toff[i]), T.w = h_w[i];
 				T.kind = GD_KIND_GENERIC, T.row_bytes = 0;
-				if (T.qlen <= 0 || T.tlen <= 0) continue; // (refused below)
+				T.qoff = h_qoff[i], T.toff = h_toff[i];
+				T.cig_off = h_cig[i], T.cig_cap = (int32_t)std::min<int64_t>(h_cig[i + 1] - h_cig[i], 0x7fffffff);
+				T.exact_score = d_exact_score ? h_ex[i] : GD_NEG_INF;
+				T.pad = 0, T.bt_off = 0;
+				if (T.qlen <= 0 || T.tlen <= 0) { S.err |= 1; continue; } // (refused below)
 				if (T.qlen == memo.qlen && T.tlen == memo.tlen && T.w == memo.w) T.kind = memo.kind, T.row_bytes = memo.row_bytes;
 				else {
 					gd_plan_one(ctx->kernel_mode, wave_scoring_ok, T.qlen, T.tlen, T.w, T.kind, T.row_bytes);
 					memo.qlen = T.qlen, memo.tlen = T.tlen, memo.w = T.w, memo.kind = T.kind, memo.row_bytes = T.row_bytes;
 				}
+				if (ctx->kernel_mode == 2 && T.kind == GD_KIND_GENERIC) S.err |= 2;
+				if (T.kind == GD_KIND_GENERIC) {
+					const int cap = gd_generic_cap(T.qlen, T.tlen, T.w);
+					if (cap * 7 > 160 * 1024 - 1024) S.err |= 4;
+					S.max_cap = std::max(S.max_cap, cap);
+				}
+				{ // accounting for the roofline: SURVEY.md 8d's per-alignment figure
+					const uint64_t wb = (uint64_t)(T.w < 0 ? std::max(T.qlen, T.tlen) : T.w) + 1;
+					const uint64_t band = std::min<uint64_t>(wb, (uint64_t)std::min(T.qlen, T.tlen));
+					const uint64_t cells = (uint64_t)(T.qlen + T.tlen - 1) * band;
+					S.cells += cells;
+					S.alg += cells + (uint64_t)(T.qlen + T.tlen) + (uint64_t)T.qlen + (uint64_t)(T.tlen + 1) / 2;
+				}
+				S.ids[T.kind].push_back(i);
+				S.mask |= T.kind == GD_KIND_GENERIC ? 2 : T.kind == GD_KIND_WAVE16 ? 4 : T.kind == GD_KIND_WAVE128 ? 8 : 1;
 			}
 		});
 	}
-	for (int i = 0; i < n; ++i) {
-		KswTask &T = h_tasks[i];
-		T.qoff = h_qoff[i], T.toff = h_toff[i];
-		T.cig_off = h_cig[i], T.cig_cap = (int32_t)std::min<int64_t>(h_cig[i + 1] - h_cig[i], 0x7fffffff);
-		T.exact_score = d_exact_score ? h_ex[i] : GD_NEG_INF;
-		T.pad = 0;
-		if (T.qlen <= 0 || T.tlen <= 0) { ctx->err = "empty sequence in batch (the reference returns without aligning)"; return GDIET_E_PARAM; }
-		if (ctx->kernel_mode == 2 && T.kind == GD_KIND_GENERIC) { ctx->err = "alignment does not fit the wave kernel"; return GDIET_E_PARAM; }
-		if (T.kind == GD_KIND_GENERIC) {
-			int cap = gd_generic_cap(T.qlen, T.tlen, T.w);
-			if (cap * 7 > 160 * 1024 - 1024) { ctx->err = "band wider than the LDS window of the generic kernel"; return GDIET_E_PARAM; }
-			max_cap = std::max(max_cap, cap);
+	plan_mark("kinds");
+	{
+		int err = 0;
+		size_t cnt[4] = {0, 0, 0, 0};
+		for (const PlanSlice &S : slices) {
+			err |= S.err, cells_sum += S.cells, alg_sum += S.alg, max_cap = std::max(max_cap, S.max_cap), ctx->last_mask |= (int)S.mask;
+			for (int k = 0; k < 4; ++k) cnt[k] += S.ids[k].size();
 		}
-		{ // accounting for the roofline: SURVEY.md 8d's per-alignment figure
-			const uint64_t wb = (uint64_t)(T.w < 0 ? std::max(T.qlen, T.tlen) : T.w) + 1;
-			const uint64_t band = std::min<uint64_t>(wb, (uint64_t)std::min(T.qlen, T.tlen));
-			const uint64_t cells = (uint64_t)(T.qlen + T.tlen - 1) * band;
-			cells_sum += cells;
-			alg_sum += cells + (uint64_t)(T.qlen + T.tlen) + (uint64_t)T.qlen + (uint64_t)(T.tlen + 1) / 2;
+		// (the first failure in the order the sequential form reported them)
+		if (err & 1) { ctx->err = "empty sequence in batch (the reference returns without aligning)"; return GDIET_E_PARAM; }
+		if (err & 2) { ctx->err = "alignment does not fit the wave kernel"; return GDIET_E_PARAM; }
+		if (err & 4) { ctx->err = "band wider than the LDS window of the generic kernel"; return GDIET_E_PARAM; }
+		for (int k = 0; k < 4; ++k) {
+			ids[k].resize(cnt[k]);
+			size_t at = 0;
+			for (const PlanSlice &S : slices) {
+				if (!S.ids[k].empty()) memcpy(ids[k].data() + at, S.ids[k].data(), S.ids[k].size() * sizeof(int32_t));
+				at += S.ids[k].size();
+			}
 		}
-		ids[T.kind].push_back(i);
-		ctx->last_mask |= T.kind == GD_KIND_GENERIC ? 2 : T.kind == GD_KIND_WAVE16 ? 4 : T.kind == GD_KIND_WAVE128 ? 8 : 1;
 	}
-	// Wide-band alignments (ONT): 134 MB of backtrace per 50 kbp alignment.  When the batch holds enough of them to fill the GPU, or their
-	// backtraces would not fit beside the rest, they run on the checkpointed kernel (snapshots + one chunk of rows: ~5 MB each,
-	// ksw_extd2_wave128c_kernel), which needs the fused backtrack.  GDIET_WIDE_CKPT=0 / 1 forces the choice.
+	plan_mark("fields");
 	bool wide_ck = false;
 	if (!ids[GD_KIND_WAVE128].empty() && ctx->fuse_bt && !(ctx->single_affine && K.q == K.q2 && K.e == K.e2)) {
 		size_t full = 0;
@@ -554,6 +588,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		if (wide_ck && T.kind == GD_KIND_WAVE128) bt += gd_align256(gd_ck_bytes(T.qlen, T.tlen, T.row_bytes) + 64);
 		else bt += gd_align256((size_t)(T.qlen + T.tlen - 1) * (size_t)T.row_bytes + 64);
 	}
+	plan_mark("bt_off");
 	// longest alignments first inside each class: the tail of the grid is then made of short jobs (a class whose members all have
 	// one geometry -- a short-read batch -- is in order already)
 	for (int k = 0; k < 4; ++k) {
@@ -589,6 +624,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		size_t at = 0;
 		for (int g : order) for (int32_t id : geos[g].members) ids[k][at++] = id;
 	}
+	plan_mark("order");
 	// checkpointed wide-band alignments whose band fits a 96-block ring (w = 1300: 83 blocks) go to the form with one block + one half
 	// block per lane; the rest (wider bands) keep two blocks per lane.  Both lists stay longest-first.  GDIET_WIDE_RING=128 forces the latter.
 	size_t n_ring96 = 0;
@@ -660,6 +696,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 			i = j;
 		}
 	}
+	plan_mark("groups");
 	ctx->h_ids.clear();
 	size_t id_off[4], group_off[3] = {0, 0, 0};
 	for (int k = 0; k < 4; ++k) {
@@ -705,6 +742,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		if (!freed || (rc = gd_grow(ctx, arena, bt))) return rc;
 		ctx->err.clear();
 	}
+	plan_mark("arena");
 	if ((rc = gd_grow(ctx, ctx->tasks, sizeof(KswTask) * n))) return rc;
 	if ((rc = gd_grow(ctx, ctx->ids, sizeof(int32_t) * ctx->h_ids.size()))) return rc;
 	if ((rc = gd_grow(ctx, ctx->status, sizeof(int32_t) * n))) return rc;
@@ -718,6 +756,7 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 		GD_HIP(hipMemcpyAsync(ctx->pipe_runs.p, ctx->h_pipe_runs.data(), sizeof(PipeRun) * ctx->h_pipe_runs.size(), hipMemcpyHostToDevice, stream));
 	}
 
+	plan_mark("upload");
 	const KswTask *d_tasks = (const KswTask *)ctx->tasks.p;
 	const int32_t *d_ids = (const int32_t *)ctx->ids.p;
 	int32_t *d_status = (int32_t *)ctx->status.p;
@@ -813,6 +852,8 @@ static int gd_ksw_batch_dev(gdiet_ctx *ctx, int n, const uint8_t *d_qseq, const 
 	} else backtrack(d_ids, (int)ctx->h_ids.size(), stream);
 	GD_HIP(hipEventRecord(ctx->ev[2], stream));
 	GD_HIP(hipGetLastError());
+	plan_mark("launch");
+	if (plan_trace) fprintf(stderr, "[gdiet dp planner, ms] n=%d%s\n", n, plan_s.c_str());
 	return GDIET_OK;
 }
 
