@@ -1,7 +1,7 @@
 // K1, short alignments as a SKEWED PIPELINE: the geometry and the per-lane pieces of ksw_extd2_pipe_kernel (ksw_pipe.hip.h), shared
 // with the host lock-step emulator (tests/emul/pipe_emul.cpp).
 //
-// A 150 x 150 short-read alignment is a FULL matrix: its band (w >= max(qlen, tlen)) never cuts anything, anti-diagonal r holds the
+// A 150 x 150 short-read alignment is a FULL matrix: its band (w >= max(qlen, tlen) - 1) never cuts anything, anti-diagonal r holds the
 // cells t in [max(0, r - qlen + 1), min(r, tlen - 1)] -- one cell on the first row, 150 in the middle, one on the last.  The grouped
 // kernels (ksw_extd2_wave_kernel<10>) give every 16-cell block of the target a lane for all qlen + tlen - 1 rows, so on average half
 // of the lanes compute cells outside the matrix.  But block j (target positions 16 j .. 16 j + 15) only holds cells of the matrix on
